@@ -1,0 +1,200 @@
+"""Known-answer tests that pin the CPU oracle.
+
+The reference's own tests (src/analyzer.rs:356-459) hold no numeric vector for this path and FFmpeg
+is not installed, so the oracle is pinned by analytic answers only: BS.1770 coefficient table,
+EBU Tech 3341 cases 1-6 and 15-19 (synthesised from their definitions), silence / short input.
+"PARITY UNPINNED" with respect to FFmpeg itself.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import signals
+
+
+def test_coefficients_match_bs1770_table(oracle):
+    k = oracle.kcoef(48000)
+    # ITU-R BS.1770-4 Table 1 / Table 2 (48 kHz)
+    assert np.allclose(k["pre_b"], [1.53512485958697, -2.69169618940638, 1.19839281085285], atol=1e-13, rtol=0)
+    assert np.allclose(k["pre_a"][1:], [-1.69065929318241, 0.73248077421585], atol=1e-13, rtol=0)
+    assert np.allclose(k["rlb_b"], [1.0, -2.0, 1.0], atol=0, rtol=0)
+    assert np.allclose(k["rlb_a"][1:], [-1.99004745483398, 0.99007225036621], atol=1e-13, rtol=0)
+
+
+def test_coefficients_other_rates(oracle):
+    # values computed independently with scipy in SURVEY.md A.1
+    k = oracle.kcoef(44100)
+    assert np.allclose(k["pre_b"], [1.53084123005035, -2.65097999515473, 1.16907907992159], atol=1e-13)
+    assert np.allclose(k["pre_a"][1:], [-1.66365511325602, 0.71259542807323], atol=1e-13)
+    assert np.allclose(k["rlb_a"][1:], [-1.98916967362980, 0.98919903578704], atol=1e-13)
+    k = oracle.kcoef(96000)
+    assert np.allclose(k["pre_a"][1:], [-1.84460946989011, 0.85584332293064], atol=1e-13)
+    assert np.allclose(k["rlb_a"][1:], [-1.99501754472472, 0.99502375904092], atol=1e-13)
+
+
+def test_kweight_gain_at_997hz_against_scipy(oracle):
+    from scipy.signal import freqz
+    k = oracle.kcoef(48000)
+    w = 2 * np.pi * 997.0 / 48000.0
+    _, h1 = freqz(k["pre_b"], k["pre_a"], worN=[w])
+    _, h2 = freqz(k["rlb_b"], k["rlb_a"], worN=[w])
+    gain_db = 20 * np.log10(abs(h1[0] * h2[0]))
+    assert abs(gain_db - 0.691) < 2e-3
+
+
+@pytest.mark.parametrize("case", [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("mode", ["ebur128", "exact", "loudnorm"])
+def test_ebu3341_integrated(oracle, case, mode):
+    pcm, exp_i, _ = signals.ebu3341_case(case)
+    gm = {"ebur128": oracle.GATE_EBUR128, "exact": oracle.GATE_EXACT, "loudnorm": oracle.GATE_LOUDNORM}[mode]
+    r = oracle.measure(pcm, 48000, gate_mode=gm, tp_mode=oracle.TP_SAMPLE)
+    assert abs(r["integrated_lufs"] - exp_i) <= 0.1, r
+
+
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_sine_level_equals_lufs(oracle, fs):
+    # stereo 997 Hz sine at A dBFS (peak) reads A LUFS: K-gain +0.691 dB cancels the -0.691 offset
+    x = signals.stereo(signals.sine(fs, 997.0, -18.0, 12.0))
+    r = oracle.measure(x, fs, gate_mode=oracle.GATE_EXACT, tp_mode=oracle.TP_SAMPLE)
+    assert abs(r["integrated_lufs"] - (-18.0)) < 0.02, r
+    r = oracle.measure(x, fs, gate_mode=oracle.GATE_EBUR128, tp_mode=oracle.TP_SAMPLE)
+    assert abs(r["integrated_lufs"] - (-18.0)) < 0.03, r
+
+
+@pytest.mark.parametrize("case", [15, 16, 17, 18, 19])
+@pytest.mark.parametrize("tp", ["swr192k", "bs1770"])
+def test_ebu3341_true_peak(oracle, case, tp):
+    pcm, _, exp_tp = signals.ebu3341_case(case)
+    mode = oracle.TP_SWR192K if tp == "swr192k" else oracle.TP_BS1770
+    r = oracle.measure(pcm, 48000, tp_mode=mode)
+    assert exp_tp - 0.4 <= r["true_peak_dbtp"] <= exp_tp + 0.2, r
+
+
+def test_true_peak_exceeds_sample_peak_for_45deg_fs4(oracle):
+    pcm, _, _ = signals.ebu3341_case(16)
+    sp = oracle.true_peak(pcm, 48000, oracle.TP_SAMPLE)
+    tp = oracle.true_peak(pcm, 48000, oracle.TP_SWR192K)
+    assert abs(20 * np.log10(sp[0]) - (-9.03)) < 0.01
+    assert abs(20 * np.log10(tp[0]) - (-6.02)) < 0.05
+
+
+def test_true_peak_44k1_uses_640_phase_bank(oracle):
+    P, step, taps = oracle.swr_bank(44100)
+    assert (P, step) == (640, 147)
+    assert taps.shape == (641, 32)
+    # phase 0 is a unit impulse at the centre tap: input samples pass through exactly
+    e = np.zeros(32)
+    e[15] = 1.0
+    assert np.array_equal(taps[0], e)
+    # entry P is phase 0 delayed by one sample; phases mirror
+    e2 = np.zeros(32)
+    e2[16] = 1.0
+    assert np.array_equal(taps[640], e2)
+    assert np.array_equal(taps[640 - 37][::-1], taps[37])
+    assert oracle.swr_bank(48000)[:2] == (4, 1)
+    assert oracle.swr_bank(96000)[:2] == (2, 1)
+    assert oracle.swr_bank(192000)[0] == 0
+    # an fs/4 45-degree sine at 44.1 kHz: true peak ~ amplitude
+    x = signals.stereo(signals.fade(signals.sine(44100, 44100 / 4, -6.0206, 1.0, 45.0), 441))
+    tp = oracle.true_peak(x, 44100, oracle.TP_SWR192K)
+    assert abs(20 * np.log10(tp[0]) - (-6.02)) < 0.05
+
+
+def test_swr_bank_interpolates_a_bandlimited_sine(oracle):
+    # the 48k bank applied to a 5 kHz sine reproduces the sine on the 192 kHz grid
+    P, step, taps = oracle.swr_bank(48000)
+    n = np.arange(256)
+    x = np.sin(2 * np.pi * 5000.0 * n / 48000.0)
+    for ph in range(4):
+        pos = 100
+        y = np.dot(x[pos - 15:pos + 17], taps[ph])
+        ref = math.sin(2 * math.pi * 5000.0 * (pos + ph / 4.0) / 48000.0)
+        assert abs(y - ref) < 2e-4
+
+
+def test_silence_and_short_input(oracle):
+    z = np.zeros((48000 * 2, 2), dtype=np.float32)
+    r = oracle.measure(z, 48000)
+    assert r["integrated_lufs"] == -math.inf and r["true_peak_dbtp"] == -math.inf
+    assert r["n_blocks"] == 17 and r["n_gated"] == 0
+    short = signals.stereo(signals.sine(48000, 1000.0, -20.0, 0.39))
+    r = oracle.measure(short, 48000)
+    assert r["n_blocks"] == 0 and r["integrated_lufs"] == -math.inf
+    assert math.isfinite(r["true_peak_dbtp"])
+    tiny = np.ones((20, 2), dtype=np.float32)
+    r = oracle.measure(tiny, 48000)  # shorter than the resampler's priming: no output samples at all
+    assert r["true_peak_dbtp"] == -math.inf
+    empty = np.zeros((0, 2), dtype=np.float32)
+    r = oracle.measure(empty, 48000)
+    assert r["n_blocks"] == 0 and r["integrated_lufs"] == -math.inf
+
+
+def test_block_count_and_hop_identity(oracle):
+    # A.6: n_blocks = floor(N/hop) - 3; literal f_ebur128 sliding window == hop-sum formulation
+    for fs, secs in ((44100, 7.35), (48000, 5.0)):
+        pcm = signals.seeded_noise(7, int(fs * secs), 2, -23.0)
+        pcm[: fs] *= 0.001  # quiet start so that gating gates
+        r = oracle.measure(pcm, fs, tp_mode=oracle.TP_SAMPLE)
+        lit = oracle.ebur128_literal(pcm, fs)
+        nh = int(fs * secs) // (fs // 10)
+        assert r["n_blocks"] == nh - 3 == lit["n_blocks"]
+        P = oracle.block_powers(oracle.hop_sums(pcm, fs), fs)
+        assert np.allclose(P, lit["block_powers"], rtol=1e-11, atol=0)
+        assert r["n_gated"] == lit["n_gated"]
+        assert abs(r["integrated_lufs"] - lit["integrated_lufs"]) < 1e-9
+        assert abs(r["rel_threshold_lufs"] - lit["rel_threshold_lufs"]) < 1e-9
+
+
+def test_gating_modes_agree_closely(oracle):
+    pcm = signals.seeded_noise(11, 48000 * 12, 2, -20.0)
+    pcm[: 48000 * 3] *= 0.003
+    ri = [oracle.measure(pcm, 48000, gate_mode=m, tp_mode=oracle.TP_SAMPLE)["integrated_lufs"]
+          for m in (oracle.GATE_EBUR128, oracle.GATE_EXACT, oracle.GATE_LOUDNORM)]
+    assert abs(ri[0] - ri[1]) < 0.011  # 0.01 LU bins, lower-edge energy
+    assert abs(ri[2] - ri[1]) < 0.06   # 0.1 LU bins, centre energy
+
+
+def test_formats_agree(oracle):
+    x = signals.seeded_noise(3, 48000 * 3, 2, -12.0)
+    rf = oracle.measure(x, 48000)
+    r16 = oracle.measure(signals.to_s16(x), 48000)
+    r24 = oracle.measure(signals.to_s24_bytes(x), 48000, channels=2, fmt=oracle.FMT_S24)
+    r64 = oracle.measure(x.astype(np.float64), 48000)
+    assert abs(rf["integrated_lufs"] - r64["integrated_lufs"]) < 1e-12
+    assert abs(rf["integrated_lufs"] - r24["integrated_lufs"]) < 1e-4
+    assert abs(rf["integrated_lufs"] - r16["integrated_lufs"]) < 1e-2
+    assert abs(rf["true_peak_dbtp"] - r24["true_peak_dbtp"]) < 1e-4
+
+
+def test_lfe_excluded_from_loudness_but_not_from_peak(oracle):
+    pcm, _, _ = signals.ebu3341_case(6)
+    base = oracle.measure(pcm, 48000)
+    pcm2 = pcm.copy()
+    pcm2[:, 3] = signals.sine(48000, 60.0, -3.0, 20.0)
+    r = oracle.measure(pcm2, 48000)
+    assert r["integrated_lufs"] == base["integrated_lufs"]
+    assert r["true_peak_dbtp"] > base["true_peak_dbtp"] + 10
+    assert abs(r["true_peak_dbtp"] - (-3.0)) < 0.05
+
+
+def test_loudnorm_path(oracle):
+    # af_loudnorm measures after resampling to 192 kHz; on a 1 kHz sine it agrees with the native-rate meter
+    x = signals.stereo(signals.sine(48000, 1000.0, -20.0, 6.0))
+    r = oracle.loudnorm_measure(x, 48000)
+    assert abs(r["integrated_lufs"] - (-20.0)) < 0.1
+    assert abs(r["true_peak_dbtp"] - (-20.0)) < 0.05
+    z = np.zeros((48000, 2), dtype=np.float32)
+    r = oracle.loudnorm_measure(z, 48000)
+    assert r["integrated_lufs"] == -math.inf  # "-inf": the case src/analyzer.rs:282-290 rejects
+
+
+def test_synth_track_is_deterministic_and_gated(oracle):
+    a = oracle.synth_track(1234, 44100, 2, 44100 * 30)
+    b = oracle.synth_track(1234, 44100, 2, 44100 * 30)
+    assert np.array_equal(a, b)
+    assert np.max(np.abs(a)) <= 1.0
+    r = oracle.measure(a, 44100)
+    assert r["n_gated"] < r["n_blocks"] or r["rel_threshold_lufs"] > -70
+    sp = 20 * np.log10(np.max(np.abs(a)))
+    assert r["true_peak_dbtp"] > sp + 0.5  # inter-sample-peak bursts
