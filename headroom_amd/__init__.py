@@ -1,0 +1,265 @@
+"""headroom_amd -- Python harness over the C ABI of the MI355X loudness / true-peak meter.
+
+The product is `libheadroom_hip.so` (HIP kernels + C ABI, include/headroom_hip.h).  This module only
+binds it with ctypes for the tests, the bench and `torch.distributed` multi-GPU drivers; it contains
+no arithmetic of its own and no fallback: importing it without the built library raises.
+"""
+import ctypes as C
+import math
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libheadroom_hip.so")
+
+MAX_CH = 8
+FMT_F32, FMT_S16, FMT_S24, FMT_S32, FMT_F64 = range(5)
+GATE_EBUR128, GATE_EXACT, GATE_LOUDNORM = range(3)
+TP_SWR192K, TP_BS1770, TP_SAMPLE = range(3)
+TRACK_DEVICE_PCM = 1
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RATE, ERR_FORMAT, ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6, -7
+GAIN_FFMPEG_LOSSLESS, GAIN_MP3_LOSSLESS, GAIN_MP3_REENCODE, GAIN_AAC_LOSSLESS, GAIN_AAC_REENCODE, GAIN_NONE = range(6)
+KIND_LOSSLESS, KIND_MP3, KIND_AAC = range(3)
+_FMT_BYTES = {FMT_F32: 4, FMT_S16: 2, FMT_S24: 3, FMT_S32: 4, FMT_F64: 8}
+_NP_FMT = {np.dtype("float32"): FMT_F32, np.dtype("int16"): FMT_S16, np.dtype("int32"): FMT_S32,
+           np.dtype("float64"): FMT_F64}
+
+
+class HrConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("gate_mode", C.c_int32), ("tp_mode", C.c_int32), ("engine", C.c_int32),
+                ("stream", C.c_void_p), ("stage_bytes", C.c_uint64)]
+
+
+class HrTrack(C.Structure):
+    _fields_ = [("pcm", C.c_void_p), ("frames", C.c_uint64), ("sample_rate", C.c_uint32), ("channels", C.c_uint16),
+                ("fmt", C.c_uint16), ("ch_weight", C.POINTER(C.c_float)), ("flags", C.c_uint32), ("reserved", C.c_uint32)]
+
+
+class HrResult(C.Structure):
+    _fields_ = [("integrated_lufs", C.c_double), ("true_peak_dbtp", C.c_double), ("rel_threshold_lufs", C.c_double),
+                ("n_blocks", C.c_uint64), ("n_gated", C.c_uint64), ("peak_per_ch", C.c_double * MAX_CH),
+                ("status", C.c_int32), ("reserved", C.c_int32)]
+
+
+class HrShardEdge(C.Structure):
+    _fields_ = [("rec", C.c_double * 9 * MAX_CH * 6), ("tail", C.c_double * MAX_CH * 16), ("n_hops", C.c_uint64)]
+
+
+class HrShardPartial(C.Structure):
+    _fields_ = [("hist", C.c_uint64 * 8001), ("sum_kept", C.c_double), ("n_kept", C.c_uint64), ("n_blocks", C.c_uint64),
+                ("peak_per_ch", C.c_double * MAX_CH)]
+
+
+class HrTpTarget(C.Structure):
+    _fields_ = [("split", C.c_int32), ("high", C.c_double), ("low", C.c_double)]
+
+
+class HrAnalysis(C.Structure):
+    _fields_ = [("input_i", C.c_double), ("input_tp", C.c_double), ("has_bitrate", C.c_int32), ("bitrate_kbps", C.c_uint32),
+                ("target_tp", C.c_double), ("headroom", C.c_double), ("gain_method", C.c_int32),
+                ("effective_gain", C.c_double), ("lossless_gain_steps", C.c_int32), ("status", C.c_int32)]
+
+
+EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
+           "hr_block_energies", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
+           "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision"]
+
+_lib = None
+
+
+def lib():
+    """Loads libheadroom_hip.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(make -C headroom_amd/csrc). The meter has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    L.hr_device_count.restype = C.c_int
+    L.hr_init.argtypes = [C.POINTER(HrConfig), C.POINTER(C.c_void_p)]
+    L.hr_destroy.argtypes = [C.c_void_p]
+    L.hr_destroy.restype = None
+    L.hr_alloc_pinned.argtypes = [C.c_size_t]
+    L.hr_alloc_pinned.restype = C.c_void_p
+    L.hr_free_pinned.argtypes = [C.c_void_p]
+    L.hr_free_pinned.restype = None
+    L.hr_analyze_batch.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_size_t, C.POINTER(HrResult)]
+    L.hr_block_energies.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double), C.c_uint64,
+                                    C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    L.hr_shard_head.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double)]
+    L.hr_shard_pass1.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                 C.c_int, C.POINTER(HrShardEdge)]
+    L.hr_shard_pass2.argtypes = [C.c_void_p, C.POINTER(HrShardEdge), C.POINTER(HrShardPartial)]
+    L.hr_shard_finish.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.c_int, C.POINTER(HrResult)]
+    L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
+    L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    L.hr_strerror.argtypes = [C.c_int]
+    L.hr_strerror.restype = C.c_char_p
+    L.hr_gain_decision.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint32, C.POINTER(HrTpTarget),
+                                   C.POINTER(HrAnalysis)]
+    _lib = L
+    return L
+
+
+class HeadroomError(RuntimeError):
+    def __init__(self, code, what=""):
+        self.code = code
+        super().__init__(f"{what}: {lib().hr_strerror(code).decode()} ({code})")
+
+
+def _check(code, what):
+    if code != OK:
+        raise HeadroomError(code, what)
+
+
+def device_count():
+    return lib().hr_device_count()
+
+
+def _result_dict(r, channels):
+    return {"integrated_lufs": r.integrated_lufs, "true_peak_dbtp": r.true_peak_dbtp,
+            "rel_threshold_lufs": r.rel_threshold_lufs, "n_blocks": int(r.n_blocks), "n_gated": int(r.n_gated),
+            "peak_per_ch": [r.peak_per_ch[i] for i in range(channels)], "status": int(r.status)}
+
+
+class TrackSpec:
+    """One PCM stream for the C ABI: numpy array (host), or a raw device pointer / torch CUDA tensor."""
+
+    def __init__(self, pcm, sample_rate, channels=None, fmt=None, weights=None, frames=None):
+        self.keep = []
+        flags = 0
+        if isinstance(pcm, np.ndarray):
+            if fmt == FMT_S24:
+                buf = np.ascontiguousarray(pcm, dtype=np.uint8)
+                frames = buf.size // (3 * channels)
+            else:
+                buf = np.ascontiguousarray(pcm)
+                if buf.ndim == 1:
+                    buf = buf[:, None]
+                frames, ch = buf.shape
+                channels = channels or ch
+                fmt = _NP_FMT[buf.dtype] if fmt is None else fmt
+            ptr = buf.ctypes.data
+            self.keep.append(buf)
+        elif hasattr(pcm, "data_ptr"):  # torch tensor
+            t = pcm
+            if t.is_cuda:
+                flags |= TRACK_DEVICE_PCM
+            assert t.is_contiguous()
+            if fmt is None:
+                import torch
+                fmt = {torch.float32: FMT_F32, torch.int16: FMT_S16, torch.int32: FMT_S32, torch.float64: FMT_F64}[t.dtype]
+            if fmt == FMT_S24:
+                frames = t.numel() // (3 * channels)
+            else:
+                if t.dim() == 1:
+                    channels = channels or 1
+                    frames = t.numel() // channels
+                else:
+                    frames, ch = t.shape
+                    channels = channels or ch
+            ptr = t.data_ptr()
+            self.keep.append(t)
+        else:  # (device pointer int, explicit geometry)
+            ptr = int(pcm)
+            flags |= TRACK_DEVICE_PCM
+            assert frames is not None and channels and fmt is not None
+        wptr = C.POINTER(C.c_float)()
+        if weights is not None:
+            w = np.ascontiguousarray(weights, dtype=np.float32)
+            self.keep.append(w)
+            wptr = w.ctypes.data_as(C.POINTER(C.c_float))
+        self.channels = channels
+        self.c = HrTrack(ptr, frames, sample_rate, channels, fmt, wptr, flags, 0)
+
+
+class Meter:
+    """A per-GPU context of the meter (hr_init / hr_destroy)."""
+
+    def __init__(self, device=0, gate_mode=GATE_EBUR128, tp_mode=TP_SWR192K, engine=0, stage_bytes=0, stream=None):
+        self._h = C.c_void_p()
+        cfg = HrConfig(device, gate_mode, tp_mode, engine, stream, stage_bytes)
+        _check(lib().hr_init(C.byref(cfg), C.byref(self._h)), "hr_init")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().hr_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def analyze_batch(self, specs):
+        n = len(specs)
+        arr = (HrTrack * max(n, 1))(*[s.c for s in specs])
+        out = (HrResult * max(n, 1))()
+        _check(lib().hr_analyze_batch(self._h, arr, n, out), "hr_analyze_batch")
+        return [_result_dict(out[i], specs[i].channels or 0) for i in range(n)]
+
+    def analyze(self, pcm, sample_rate, **kw):
+        return self.analyze_batch([TrackSpec(pcm, sample_rate, **kw)])[0]
+
+    def block_energies(self, spec):
+        hop = spec.c.sample_rate // 10
+        nh = spec.c.frames // hop if hop else 0
+        H = np.zeros((max(nh, 1), spec.channels), dtype=np.float64)
+        P = np.zeros(max(nh, 1), dtype=np.float64)
+        n_h, n_b = C.c_uint64(), C.c_uint64()
+        _check(lib().hr_block_energies(self._h, C.byref(spec.c), H.ctypes.data_as(C.POINTER(C.c_double)), nh,
+                                       P.ctypes.data_as(C.POINTER(C.c_double)), nh, C.byref(n_h), C.byref(n_b)),
+               "hr_block_energies")
+        return H[:n_h.value], P[:n_b.value]
+
+    def synth_fill(self, device_ptr, seed, sample_rate, channels, frames):
+        _check(lib().hr_synth_fill(self._h, C.c_void_p(int(device_ptr)), seed, sample_rate, channels, frames), "hr_synth_fill")
+
+    def last_timing(self):
+        a, b = C.c_float(), C.c_float()
+        lib().hr_last_timing(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    # ---- time shards (one process per GPU; the exchange is the caller's: torch.distributed) ----
+    def shard_head(self, spec):
+        head = np.zeros((16, MAX_CH), dtype=np.float64)
+        _check(lib().hr_shard_head(self._h, C.byref(spec.c), head.ctypes.data_as(C.POINTER(C.c_double))), "hr_shard_head")
+        return head
+
+    def shard_pass1(self, spec, left_tail, right_head):
+        edge = HrShardEdge()
+        lp = left_tail.ctypes.data_as(C.POINTER(C.c_double)) if left_tail is not None else None
+        rp = right_head.ctypes.data_as(C.POINTER(C.c_double)) if right_head is not None else None
+        _check(lib().hr_shard_pass1(self._h, C.byref(spec.c), lp, rp, int(left_tail is None), int(right_head is None),
+                                    C.byref(edge)), "hr_shard_pass1")
+        return edge
+
+    def shard_pass2(self, left_edge):
+        part = HrShardPartial()
+        _check(lib().hr_shard_pass2(self._h, C.byref(left_edge) if left_edge is not None else None, C.byref(part)),
+               "hr_shard_pass2")
+        return part
+
+    def shard_finish(self, partial, channels):
+        r = HrResult()
+        _check(lib().hr_shard_finish(self._h, C.byref(partial), channels, C.byref(r)), "hr_shard_finish")
+        return _result_dict(r, channels)
+
+
+def gain_decision(input_i, input_tp, kind=KIND_LOSSLESS, bitrate_kbps=None, split=None):
+    """src/analyzer.rs:284-326 through the C ABI.  split = (high, low) selects SplitBitrate."""
+    mode = HrTpTarget(1, split[0], split[1]) if split else None
+    out = HrAnalysis()
+    rc = lib().hr_gain_decision(input_i, input_tp, kind, int(bitrate_kbps is not None), int(bitrate_kbps or 0),
+                                C.byref(mode) if mode else None, C.byref(out))
+    return rc, {f: getattr(out, f) for f, _ in HrAnalysis._fields_}

@@ -1,0 +1,68 @@
+// hr_analyzer.cpp -- host-side mirror of the analyzer's scalar logic.
+//
+// Follows src/analyzer.rs:16-33 (constants), :157-187 (TpTargetMode::target_for) and :284-326 (finite
+// check and gain decision).  GAIN_STEP is mp3rgain::GAIN_STEP_DB (src/analyzer.rs:29; mp3rgain 2.9.1,
+// Cargo.lock:961-964; README.md:282 states the value: 1.5 dB, fixed by the MP3/AAC global_gain step).
+#include <cmath>
+
+#include "../../include/headroom_hip.h"
+
+namespace {
+constexpr unsigned kHighBitrateThreshold = 256;  // analyzer.rs:26
+constexpr double kGainStep = 1.5;                // analyzer.rs:29
+constexpr double kMinEffectiveGain = 0.05;       // analyzer.rs:33
+
+double target_for(const hr_tp_target &m, bool is_lossy, bool has_bitrate, unsigned kbps)
+{
+    if (!m.split) return m.high;              // Uniform(t)
+    if (!is_lossy) return m.high;             // SplitBitrate: lossless -> high
+    if (has_bitrate && kbps >= kHighBitrateThreshold) return m.high;
+    return m.low;
+}
+}  // namespace
+
+extern "C" int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
+                                const hr_tp_target *mode, hr_analysis *out)
+{
+    if (!out || kind < HR_KIND_LOSSLESS || kind > HR_KIND_AAC) return HR_ERR_INVALID;
+    hr_tp_target m{0, -0.5, -1.0};  // DEFAULT_TARGET_TRUE_PEAK, analyzer.rs:16
+    if (mode) m = *mode;
+    *out = hr_analysis{};
+    out->input_i = input_i;
+    out->input_tp = input_tp;
+    // analyzer.rs:284-290: loudnorm reports "-inf" for silent audio; reject non-finite values
+    if (!std::isfinite(input_i) || !std::isfinite(input_tp)) {
+        out->status = HR_ERR_INVALID;
+        out->gain_method = HR_GAIN_NONE;
+        return HR_ERR_INVALID;
+    }
+    const bool is_mp3 = kind == HR_KIND_MP3, is_aac = kind == HR_KIND_AAC;
+    const bool is_lossy = is_mp3 || is_aac;
+    // analyzer.rs:298-302: bitrate only matters (and is only looked up) for lossy files
+    out->has_bitrate = is_lossy && has_bitrate;
+    out->bitrate_kbps = out->has_bitrate ? bitrate_kbps : 0;
+    out->target_tp = target_for(m, is_lossy, out->has_bitrate, out->bitrate_kbps);
+    out->headroom = out->target_tp - input_tp;
+    if (out->headroom < kMinEffectiveGain) {
+        out->gain_method = HR_GAIN_NONE;
+        out->effective_gain = 0.0;
+        out->lossless_gain_steps = 0;
+    } else if (!is_lossy) {
+        out->gain_method = HR_GAIN_FFMPEG_LOSSLESS;
+        out->effective_gain = out->headroom;
+        out->lossless_gain_steps = 0;
+    } else {
+        const int steps = static_cast<int>(std::floor(out->headroom / kGainStep));
+        if (steps >= 1) {
+            out->gain_method = is_aac ? HR_GAIN_AAC_LOSSLESS : HR_GAIN_MP3_LOSSLESS;
+            out->effective_gain = static_cast<double>(steps) * kGainStep;
+            out->lossless_gain_steps = steps;
+        } else {
+            out->gain_method = is_aac ? HR_GAIN_AAC_REENCODE : HR_GAIN_MP3_REENCODE;
+            out->effective_gain = out->headroom;
+            out->lossless_gain_steps = 0;
+        }
+    }
+    out->status = HR_OK;
+    return HR_OK;
+}

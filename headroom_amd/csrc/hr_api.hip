@@ -1,0 +1,745 @@
+// hr_api.hip -- the C ABI of include/headroom_hip.h: context, device tables, batch driver.
+//
+// Mirrors, on the reference side: analyze_files (src/cli.rs:403-435: order-preserving batch, per-track
+// errors do not fail the batch) and the measurement half of analyze_file_with_target
+// (src/analyzer.rs:253-290).  There is no CPU fallback: without a HIP device hr_init fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <vector>
+
+#include "../../include/headroom_hip.h"
+#include "hr_device.hpp"
+#include "hr_kernels.hpp"
+#include "hr_tables.hpp"
+
+using namespace hr;
+
+namespace {
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    // grow-only; returns false on allocation failure
+    bool ensure(size_t bytes)
+    {
+        if (bytes <= cap) return true;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = bytes + bytes / 4 + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) {
+            (void)hipGetLastError();
+            want = bytes;
+            if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        }
+        cap = want;
+        return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    template <class T> T *as() const { return static_cast<T *>(p); }
+};
+
+size_t fmt_bytes(int fmt)
+{
+    switch (fmt) {
+    case HR_FMT_F32: return 4;
+    case HR_FMT_S16: return 2;
+    case HR_FMT_S24: return 3;
+    case HR_FMT_S32: return 4;
+    case HR_FMT_F64: return 8;
+    default: return 0;
+    }
+}
+
+}  // namespace
+
+namespace { struct Group; }
+
+struct hr_ctx {
+    hr_config cfg{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::mutex mu;
+
+    // device tables
+    std::vector<uint32_t> rate_fs;
+    std::vector<RateDev> rates_h;
+    std::vector<void *> rate_allocs;
+    DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
+
+    // workspace (grow-only)
+    DevBuf tracks_d, items_d, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+
+    // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
+    std::vector<WorkItem> h_items;
+
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float last_total_ms = 0, last_main_ms = 0;
+
+    size_t comb_off = 0, comb_n = 0;  // combine work items of the last run_measure
+
+    // state of an open time shard (hr_shard_pass1 .. hr_shard_pass2)
+    bool shard_open = false;
+    Group *shard_group = nullptr;
+};
+
+#define HIPCHK(expr)                                                                      \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess) {                                                          \
+            std::fprintf(stderr, "headroom_hip: %s failed: %s\n", #expr, hipGetErrorString(e__)); \
+            (void)hipGetLastError();                                                      \
+            return e__ == hipErrorOutOfMemory ? HR_ERR_OOM : HR_ERR_HIP;                  \
+        }                                                                                 \
+    } while (0)
+
+namespace {
+
+int upload(DevBuf &b, const void *src, size_t bytes, hipStream_t st)
+{
+    if (!b.ensure(bytes)) return HR_ERR_OOM;
+    HIPCHK(hipMemcpyAsync(b.p, src, bytes, hipMemcpyHostToDevice, st));
+    return HR_OK;
+}
+
+// device tables of one sample rate; returns the index in ctx->rates_h or a negative error
+int rate_index(hr_ctx *ctx, uint32_t fs)
+{
+    for (size_t i = 0; i < ctx->rate_fs.size(); i++)
+        if (ctx->rate_fs[i] == fs) return static_cast<int>(i);
+    const RateTables *rt = rate_tables(fs);
+    if (!rt || rt->hop == 0) return HR_ERR_RATE;
+    RateDev rd{};
+    rd.k = rt->k;
+    std::memcpy(rd.G, rt->G, sizeof rd.G);
+    std::memcpy(rd.M1, rt->M[0], sizeof rd.M1);
+    std::memcpy(rd.M2, rt->M[1], sizeof rd.M2);
+    rd.hop = rt->hop;
+    rd.swr_phases = rt->swr_phases;
+    rd.swr_step = rt->swr_step;
+    rd.swr_l1 = rt->swr_l1;
+    void *g = nullptr;
+    HIPCHK(hipMalloc(&g, rt->g.size() * sizeof(double)));
+    ctx->rate_allocs.push_back(g);
+    HIPCHK(hipMemcpy(g, rt->g.data(), rt->g.size() * sizeof(double), hipMemcpyHostToDevice));
+    rd.g = static_cast<const double *>(g);
+    if (rt->swr_phases > 0) {
+        void *tp = nullptr, *tp32 = nullptr;
+        HIPCHK(hipMalloc(&tp, rt->swr_taps.size() * sizeof(double)));
+        ctx->rate_allocs.push_back(tp);
+        HIPCHK(hipMemcpy(tp, rt->swr_taps.data(), rt->swr_taps.size() * sizeof(double), hipMemcpyHostToDevice));
+        std::vector<float> t32(rt->swr_taps.begin(), rt->swr_taps.end());
+        HIPCHK(hipMalloc(&tp32, t32.size() * sizeof(float)));
+        ctx->rate_allocs.push_back(tp32);
+        HIPCHK(hipMemcpy(tp32, t32.data(), t32.size() * sizeof(float), hipMemcpyHostToDevice));
+        rd.swr_taps = static_cast<const double *>(tp);
+        rd.swr_taps32 = static_cast<const float *>(tp32);
+    }
+    ctx->rate_fs.push_back(fs);
+    ctx->rates_h.push_back(rd);
+    if (!ctx->rates_d.ensure(ctx->rates_h.size() * sizeof(RateDev) + 16 * sizeof(RateDev))) return HR_ERR_OOM;
+    HIPCHK(hipMemcpy(ctx->rates_d.p, ctx->rates_h.data(), ctx->rates_h.size() * sizeof(RateDev), hipMemcpyHostToDevice));
+    return static_cast<int>(ctx->rates_h.size() - 1);
+}
+
+int validate_track(const hr_ctx *ctx, const hr_track &t)
+{
+    if (t.channels < 1 || t.channels > HR_MAX_CH) return HR_ERR_FORMAT;
+    if (fmt_bytes(t.fmt) == 0) return HR_ERR_FORMAT;
+    if (t.sample_rate < 10) return HR_ERR_RATE;
+    if (t.frames && !t.pcm) return HR_ERR_INVALID;
+    if (ctx->cfg.tp_mode == HR_TP_SWR192K) {
+        const RateTables *rt = rate_tables(t.sample_rate);
+        if (!rt || rt->swr_phases < 0) return HR_ERR_RATE;  // would need libswresample's phase interpolation
+    }
+    return HR_OK;
+}
+
+// One launch group: descriptors already built in `descs` (host), PCM resident on the device.
+struct Group {
+    std::vector<TrackDesc> descs;
+    std::vector<int> fmts;  // per desc
+    uint64_t rec_slots = 0, hop_slots = 0, blk_slots = 0;  // totals: (hop, channel) records / sums, blocks
+};
+
+void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bool stream_start, bool stream_end,
+              bool has_left, uint64_t stream_frames, int tp_mode)
+{
+    TrackDesc d{};
+    d.pcm = dev_pcm;
+    d.frames = t.frames;
+    d.fs = t.sample_rate;
+    d.hop = t.sample_rate / 10;
+    d.n_hops = t.frames / d.hop;
+    d.ch = t.channels;
+    d.fmt = t.fmt;
+    d.rate_idx = rate_idx;
+    d.stream_start = stream_start;
+    d.stream_end = stream_end;
+    d.tp_enabled = tp_mode != HR_TP_SWR192K || stream_frames >= kSwrTaps + 1;
+    d.blk_first = has_left ? -kPreHop : 0;
+    const int64_t hops_avail = static_cast<int64_t>(d.n_hops) + (has_left ? kPreHop : 0);
+    d.n_blocks = hops_avail >= 4 ? static_cast<uint64_t>(hops_avail - 3) : 0;
+    d.rec_base = g.rec_slots;
+    d.hop_base = g.hop_slots;
+    d.blk_base = g.blk_slots;
+    g.rec_slots += (d.n_hops + kPreRec) * d.ch;
+    g.hop_slots += (d.n_hops + kPreHop) * d.ch;
+    g.blk_slots += d.n_blocks;
+    if (t.ch_weight) for (int c = 0; c < t.channels; c++) d.w[c] = t.ch_weight[c];
+    else default_weights(t.channels, d.w);
+    g.descs.push_back(d);
+    g.fmts.push_back(t.fmt);
+}
+
+// Runs K-weight + combine (+ true peak) for a group.  Leaves hop sums / peaks on the device.
+int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nt = g.descs.size();
+    if (!nt) return HR_OK;
+    if (!ctx->recs.ensure((g.rec_slots + 8) * sizeof(HopRec))) return HR_ERR_OOM;
+    if (!ctx->hop_sums.ensure((g.hop_slots + 8) * sizeof(double))) return HR_ERR_OOM;
+    if (!ctx->blk_powers.ensure(std::max<uint64_t>(g.blk_slots, 1) * sizeof(double))) return HR_ERR_OOM;
+    if (!ctx->peaks.ensure(nt * kMaxCh * sizeof(unsigned long long))) return HR_ERR_OOM;
+    int rc = upload(ctx->tracks_d, g.descs.data(), nt * sizeof(TrackDesc), st);
+    if (rc) return rc;
+    const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
+    const RateDev *dr = ctx->rates_d.as<RateDev>();
+
+    // work items: [fmt] hop items, combine items, [fmt][kind] peak items -- one upload
+    std::vector<WorkItem> &items = ctx->h_items;
+    items.clear();
+    struct Span { size_t off, n; };
+    Span hop_span[5], pk_span[5][2], comb_span;
+    for (int f = 0; f < 5; f++) {
+        hop_span[f].off = items.size();
+        for (size_t i = 0; i < nt; i++) {
+            if (g.fmts[i] != f) continue;
+            for (uint64_t h = 0; h < g.descs[i].n_hops; h += 256) items.push_back({static_cast<uint32_t>(i), 0, h});
+        }
+        hop_span[f].n = items.size() - hop_span[f].off;
+    }
+    comb_span.off = items.size();
+    for (size_t i = 0; i < nt; i++) {
+        const auto &d = g.descs[i];
+        const uint64_t pairs = (d.n_hops + (d.blk_first < 0 ? kPreHop : 0)) * d.ch;
+        for (uint64_t p = 0; p < pairs; p += 256) items.push_back({static_cast<uint32_t>(i), 0, p});
+    }
+    comb_span.n = items.size() - comb_span.off;
+    // kind 0 = the configured interpolator, kind 1 = sample peak (192 kHz input under HR_TP_SWR192K:
+    // libswresample does not resample, f_ebur128's "true peak" is then the sample peak)
+    for (int f = 0; f < 5; f++)
+        for (int kind = 0; kind < 2; kind++) {
+            pk_span[f][kind].off = items.size();
+            if (do_peaks)
+                for (size_t i = 0; i < nt; i++) {
+                    if (g.fmts[i] != f) continue;
+                    const bool plain = ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0;
+                    if (plain != (kind == 1)) continue;
+                    for (uint64_t n = 0; n < g.descs[i].frames; n += 256) items.push_back({static_cast<uint32_t>(i), 0, n});
+                }
+            pk_span[f][kind].n = items.size() - pk_span[f][kind].off;
+        }
+    if (!items.empty()) {
+        rc = upload(ctx->items_d, items.data(), items.size() * sizeof(WorkItem), st);
+        if (rc) return rc;
+    }
+    const WorkItem *di = ctx->items_d.as<WorkItem>();
+
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    for (int f = 0; f < 5; f++)
+        launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), st);
+    if (do_peaks) {
+        HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
+        for (int f = 0; f < 5; f++)
+            for (int kind = 0; kind < 2; kind++) {
+                if (!pk_span[f][kind].n) continue;
+                launch_true_peak_generic(f, kind == 1 ? HR_TP_SAMPLE : ctx->cfg.tp_mode, dt, dr, ctx->bs_taps.as<double>(),
+                                         di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n),
+                                         ctx->peaks.as<unsigned long long>(), st);
+            }
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    ctx->comb_off = comb_span.off;
+    ctx->comb_n = comb_span.n;
+    if (do_combine)
+        launch_hop_combine(dt, dr, di + comb_span.off, static_cast<uint32_t>(comb_span.n), ctx->recs.as<HopRec>(),
+                           ctx->hop_sums.as<double>(), st);
+    HIPCHK(hipGetLastError());
+    return HR_OK;
+}
+
+int run_gating(hr_ctx *ctx, Group &g, bool finalize)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t nt = static_cast<uint32_t>(g.descs.size());
+    if (!nt) return HR_OK;
+    if (!ctx->hist.ensure(static_cast<size_t>(nt) * kEbuBins * sizeof(uint32_t))) return HR_ERR_OOM;
+    if (!ctx->outs.ensure(static_cast<size_t>(nt) * sizeof(TrackOut))) return HR_ERR_OOM;
+    const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
+    launch_block_hist(dt, nt, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
+                      ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->outs.as<TrackOut>(), st);
+    if (finalize)
+        launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
+                          ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
+                          ctx->outs.as<TrackOut>(), st);
+    HIPCHK(hipGetLastError());
+    return HR_OK;
+}
+
+void fill_result(const hr_ctx *ctx, const TrackOut &o, const unsigned long long *pk, int channels, hr_result *r)
+{
+    const double ninf = -std::numeric_limits<double>::infinity();
+    r->n_blocks = o.n_blocks;
+    r->n_gated = o.n_kept;
+    r->integrated_lufs = ninf;
+    r->rel_threshold_lufs = ninf;
+    const int gm = ctx->cfg.gate_mode;
+    if (o.n_kept) {
+        if (gm == HR_GATE_EBUR128) r->rel_threshold_lufs = (-0.691 + 10.0 * std::log10(o.rel_energy)) + (-10.0);
+        else if (gm == HR_GATE_LOUDNORM) r->rel_threshold_lufs = 10.0 * (std::log(o.rel_energy * 0.1) / std::log(10.0)) - 0.691;
+        else r->rel_threshold_lufs = -0.691 + 10.0 * std::log10(0.1 * o.rel_energy);
+        if (o.n_gated_final) {
+            if (gm == HR_GATE_LOUDNORM) r->integrated_lufs = 10.0 * (std::log(o.mean_energy) / std::log(10.0)) - 0.691;
+            else r->integrated_lufs = -0.691 + 10.0 * std::log10(o.mean_energy);
+        }
+    }
+    double m = 0.0;
+    for (int c = 0; c < HR_MAX_CH; c++) r->peak_per_ch[c] = 0.0;
+    for (int c = 0; c < channels; c++) {
+        double v;
+        std::memcpy(&v, &pk[c], sizeof v);
+        r->peak_per_ch[c] = v;
+        if (v > m) m = v;
+    }
+    r->true_peak_dbtp = 20.0 * std::log10(m);
+    r->status = HR_OK;
+}
+
+// Stages the host-resident tracks of [begin, end) and measures the group.
+int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t> &idx, hr_result *out)
+{
+    hipStream_t st = ctx->stream;
+    Group g;
+    // staging layout
+    size_t stage_need = 0;
+    std::vector<size_t> off(idx.size(), 0);
+    for (size_t k = 0; k < idx.size(); k++) {
+        const hr_track &t = tracks[idx[k]];
+        if (t.flags & HR_TRACK_DEVICE_PCM) continue;
+        off[k] = stage_need;
+        stage_need += (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
+    }
+    if (stage_need && !ctx->stage.ensure(stage_need)) return HR_ERR_OOM;
+    for (size_t k = 0; k < idx.size(); k++) {
+        const hr_track &t = tracks[idx[k]];
+        const void *dev = t.pcm;
+        if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
+            dev = static_cast<char *>(ctx->stage.p) + off[k];
+            const size_t bytes = t.frames * t.channels * fmt_bytes(t.fmt);
+            if (bytes) HIPCHK(hipMemcpyAsync(const_cast<void *>(dev), t.pcm, bytes, hipMemcpyHostToDevice, st));
+        }
+        const int ri = rate_index(ctx, t.sample_rate);
+        if (ri < 0) return ri;
+        add_desc(g, t, dev, ri, true, true, false, t.frames, ctx->cfg.tp_mode);
+    }
+    int rc = run_measure(ctx, g, true);
+    if (rc) return rc;
+    rc = run_gating(ctx, g, true);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(ctx->ev[1], st));
+    const size_t nt = g.descs.size();
+    std::vector<TrackOut> outs(nt);
+    std::vector<unsigned long long> pk(nt * kMaxCh);
+    HIPCHK(hipMemcpyAsync(outs.data(), ctx->outs.p, nt * sizeof(TrackOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_total_ms += ms;
+    if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_main_ms += ms;
+    for (size_t k = 0; k < nt; k++) fill_result(ctx, outs[k], &pk[k * kMaxCh], tracks[idx[k]].channels, &out[idx[k]]);
+    return HR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int hr_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+int hr_init(const hr_config *cfg, hr_ctx **out)
+{
+    if (!out) return HR_ERR_INVALID;
+    *out = nullptr;
+    hr_config c{};
+    if (cfg) c = *cfg;
+    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2) return HR_ERR_INVALID;
+    const int n = hr_device_count();
+    if (n <= 0) return HR_ERR_NO_DEVICE;
+    if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;
+    HIPCHK(hipSetDevice(c.device));
+    hr_ctx *ctx = new hr_ctx();
+    ctx->cfg = c;
+    if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
+    if (c.stream) ctx->stream = static_cast<hipStream_t>(c.stream);
+    else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HR_ERR_HIP; }
+        ctx->own_stream = true;
+    }
+    for (auto &e : ctx->ev)
+        if (hipEventCreate(&e) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
+    int rc = upload(ctx->ebu_energy, ebur128_bin_energy().data(), kEbuBins * sizeof(double), ctx->stream);
+    if (!rc) rc = upload(ctx->ln_energy, loudnorm_bin_energy().data(), kLnBins * sizeof(double), ctx->stream);
+    if (!rc) rc = upload(ctx->ln_bounds, loudnorm_bin_bounds().data(), (kLnBins + 1) * sizeof(double), ctx->stream);
+    if (!rc) rc = upload(ctx->bs_taps, bs1770_taps(), 48 * sizeof(double), ctx->stream);
+    if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HR_ERR_HIP;
+    if (rc) { hr_destroy(ctx); return rc; }
+    *out = ctx;
+    return HR_OK;
+}
+
+void hr_destroy(hr_ctx *ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->cfg.device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
+                      &ctx->items_d, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->stage, &ctx->halos})
+        b->release();
+    for (void *p : ctx->rate_allocs) (void)hipFree(p);
+    delete ctx->shard_group;
+    for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void *hr_alloc_pinned(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void hr_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
+
+int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out)
+{
+    if (!ctx || (n && (!tracks || !out))) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    ctx->last_total_ms = ctx->last_main_ms = 0;
+    const double ninf = -std::numeric_limits<double>::infinity();
+    std::vector<size_t> cur;
+    size_t cur_bytes = 0;
+    int fatal = HR_OK;
+    auto flush = [&]() {
+        if (cur.empty() || fatal) { cur.clear(); cur_bytes = 0; return; }
+        const int rc = analyze_group(ctx, tracks, cur, out);
+        if (rc) {
+            // a failing group marks its own tracks; HIP errors are fatal for the call
+            for (size_t i : cur) out[i].status = rc;
+            if (rc == HR_ERR_HIP) fatal = rc;
+        }
+        cur.clear();
+        cur_bytes = 0;
+    };
+    for (size_t i = 0; i < n; i++) {
+        std::memset(&out[i], 0, sizeof out[i]);
+        out[i].integrated_lufs = out[i].true_peak_dbtp = out[i].rel_threshold_lufs = ninf;
+        const int v = validate_track(ctx, tracks[i]);
+        if (v) { out[i].status = v; continue; }
+        const size_t bytes = (tracks[i].flags & HR_TRACK_DEVICE_PCM)
+                                 ? 0 : tracks[i].frames * tracks[i].channels * fmt_bytes(tracks[i].fmt) + 256;
+        if (!cur.empty() && cur_bytes + bytes > ctx->cfg.stage_bytes) flush();
+        cur.push_back(i);
+        cur_bytes += bytes;
+    }
+    flush();
+    return fatal;
+}
+
+int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint64_t cap_hops, double *block_powers,
+                      uint64_t cap_blocks, uint64_t *n_hops, uint64_t *n_blocks)
+{
+    if (!ctx || !track) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const int v = validate_track(ctx, *track);
+    if (v) return v;
+    hipStream_t st = ctx->stream;
+    Group g;
+    const void *dev = track->pcm;
+    const size_t bytes = track->frames * track->channels * fmt_bytes(track->fmt);
+    if (!(track->flags & HR_TRACK_DEVICE_PCM)) {
+        if (!ctx->stage.ensure(bytes + 256)) return HR_ERR_OOM;
+        dev = ctx->stage.p;
+        if (bytes) HIPCHK(hipMemcpyAsync(ctx->stage.p, track->pcm, bytes, hipMemcpyHostToDevice, st));
+    }
+    const int ri = rate_index(ctx, track->sample_rate);
+    if (ri < 0) return ri;
+    add_desc(g, *track, dev, ri, true, true, false, track->frames, ctx->cfg.tp_mode);
+    int rc = run_measure(ctx, g, false);
+    if (rc) return rc;
+    rc = run_gating(ctx, g, false);
+    if (rc) return rc;
+    const TrackDesc &d = g.descs[0];
+    if (n_hops) *n_hops = d.n_hops;
+    if (n_blocks) *n_blocks = d.n_blocks;
+    if (hop_sums) {
+        const uint64_t nh = std::min<uint64_t>(d.n_hops, cap_hops);
+        if (nh) HIPCHK(hipMemcpyAsync(hop_sums, ctx->hop_sums.as<double>() + d.hop_base + kPreHop * d.ch,
+                                      nh * d.ch * sizeof(double), hipMemcpyDeviceToHost, st));
+    }
+    if (block_powers) {
+        const uint64_t nb = std::min<uint64_t>(d.n_blocks, cap_blocks);
+        if (nb) HIPCHK(hipMemcpyAsync(block_powers, ctx->blk_powers.as<double>() + d.blk_base, nb * sizeof(double),
+                                      hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    return HR_OK;
+}
+
+static double raw_to_double(const unsigned char *p, int fmt)
+{
+    double x = 0;
+    switch (fmt) {
+    case HR_FMT_F32: { float f; std::memcpy(&f, p, 4); x = f; } break;
+    case HR_FMT_S16: { int16_t q; std::memcpy(&q, p, 2); x = q * (1.0 / 32768.0); } break;
+    case HR_FMT_S24: {
+        const int32_t q = static_cast<int32_t>(static_cast<uint32_t>(p[0]) << 8 | static_cast<uint32_t>(p[1]) << 16 |
+                                               static_cast<uint32_t>(p[2]) << 24);
+        x = q * (1.0 / 2147483648.0);
+    } break;
+    case HR_FMT_S32: { int32_t q; std::memcpy(&q, p, 4); x = q * (1.0 / 2147483648.0); } break;
+    default: std::memcpy(&x, p, 8); break;
+    }
+    return x;
+}
+
+int hr_shard_head(hr_ctx *ctx, const hr_track *shard, double *head)
+{
+    if (!ctx || !shard || !head) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    const int v = validate_track(ctx, *shard);
+    if (v) return v;
+    const int C = shard->channels;
+    const size_t fb = fmt_bytes(shard->fmt);
+    const uint64_t tf = std::min<uint64_t>(shard->frames, kHalo);
+    std::vector<unsigned char> raw(tf * C * fb + 8);
+    if (tf) {
+        if (shard->flags & HR_TRACK_DEVICE_PCM) HIPCHK(hipMemcpy(raw.data(), shard->pcm, tf * C * fb, hipMemcpyDeviceToHost));
+        else std::memcpy(raw.data(), shard->pcm, tf * C * fb);
+    }
+    for (int k = 0; k < kHalo; k++)
+        for (int c = 0; c < HR_MAX_CH; c++)
+            head[k * HR_MAX_CH + c] = (static_cast<uint64_t>(k) < tf && c < C) ? raw_to_double(raw.data() + (k * C + c) * fb, shard->fmt) : 0.0;
+    return HR_OK;
+}
+
+int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
+                   int is_last, hr_shard_edge *edge)
+{
+    if (!ctx || !shard || !edge) return HR_ERR_INVALID;
+    if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
+    const int v = validate_track(ctx, *shard);
+    if (v) return v;
+    const uint32_t hop = shard->sample_rate / 10;
+    const uint64_t nh = shard->frames / hop;
+    if (!is_last && (shard->frames % hop || nh < kPreRec)) return HR_ERR_INVALID;
+    hipStream_t st = ctx->stream;
+    const int C = shard->channels;
+    const size_t fb = fmt_bytes(shard->fmt);
+    const size_t bytes = shard->frames * C * fb;
+    const void *dev = shard->pcm;
+    if (!(shard->flags & HR_TRACK_DEVICE_PCM)) {
+        if (!ctx->stage.ensure(bytes + 256)) return HR_ERR_OOM;
+        dev = ctx->stage.p;
+        if (bytes) HIPCHK(hipMemcpyAsync(ctx->stage.p, shard->pcm, bytes, hipMemcpyHostToDevice, st));
+    }
+    if (!ctx->halos.ensure(2 * kHalo * kMaxCh * sizeof(double))) return HR_ERR_OOM;
+    double *halo_l = ctx->halos.as<double>(), *halo_r = halo_l + kHalo * kMaxCh;
+    // the ABI hands halos over as [16][HR_MAX_CH]; the kernels read them packed [16][channels]
+    std::vector<double> packed(2 * kHalo * C, 0.0);
+    for (int k = 0; k < kHalo; k++)
+        for (int c = 0; c < C; c++) {
+            if (!is_first) packed[k * C + c] = left_tail[k * HR_MAX_CH + c];
+            if (!is_last) packed[(kHalo + k) * C + c] = right_head[k * HR_MAX_CH + c];
+        }
+    HIPCHK(hipMemcpyAsync(halo_l, packed.data(), kHalo * C * sizeof(double), hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(halo_r, packed.data() + kHalo * C, kHalo * C * sizeof(double), hipMemcpyHostToDevice, st));
+    const int ri = rate_index(ctx, shard->sample_rate);
+    if (ri < 0) return ri;
+    delete ctx->shard_group;
+    ctx->shard_group = new Group();
+    Group &g = *ctx->shard_group;
+    add_desc(g, *shard, dev, ri, is_first != 0, is_last != 0, !is_first, ~0ull, ctx->cfg.tp_mode);
+    g.descs[0].left_tail = is_first ? nullptr : halo_l;
+    g.descs[0].right_head = is_last ? nullptr : halo_r;
+    ctx->last_total_ms = ctx->last_main_ms = 0;
+    int rc = run_measure(ctx, g, true, false);
+    if (rc) return rc;
+    // right edge: last 6 hop records and the last 16 frames
+    std::memset(edge, 0, sizeof *edge);
+    edge->n_hops = nh;
+    const TrackDesc &d = g.descs[0];
+    const uint64_t take = std::min<uint64_t>(nh, kPreRec);
+    std::vector<HopRec> tmp(take * C);
+    if (take)
+        HIPCHK(hipMemcpyAsync(tmp.data(), ctx->recs.as<HopRec>() + d.rec_base + (kPreRec + nh - take) * C,
+                              take * C * sizeof(HopRec), hipMemcpyDeviceToHost, st));
+    const uint64_t tf = std::min<uint64_t>(shard->frames, kHalo);
+    std::vector<unsigned char> raw(tf * C * fb + 8);
+    if (tf)
+        HIPCHK(hipMemcpyAsync(raw.data(), static_cast<const char *>(dev) + (shard->frames - tf) * C * fb, tf * C * fb,
+                              hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    for (uint64_t k = 0; k < take; k++)
+        for (int c = 0; c < C; c++) {
+            const HopRec &r = tmp[k * C + c];
+            double *o = edge->rec[kPreRec - take + k][c];
+            o[0] = r.e0;
+            for (int j = 0; j < 4; j++) { o[1 + j] = r.q[j]; o[5 + j] = r.s[j]; }
+        }
+    for (uint64_t k = 0; k < tf; k++)
+        for (int c = 0; c < C; c++) {
+            const double x = raw_to_double(raw.data() + (k * C + c) * fb, shard->fmt);
+            edge->tail[kHalo - tf + k][c] = x;
+        }
+    ctx->shard_open = true;
+    return HR_OK;
+}
+
+int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *partial)
+{
+    if (!ctx || !partial) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->shard_open || !ctx->shard_group) return HR_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->stream;
+    Group &g = *ctx->shard_group;
+    TrackDesc &d = g.descs[0];
+    const int C = d.ch;
+    const bool has_left = d.blk_first < 0;
+    if (has_left != (left != nullptr)) return HR_ERR_INVALID;
+    std::vector<HopRec> pre(kPreRec * C);
+    if (left) {
+        for (int k = 0; k < kPreRec; k++)
+            for (int c = 0; c < C; c++) {
+                HopRec &r = pre[k * C + c];
+                const double *o = left->rec[k][c];
+                r.e0 = o[0];
+                for (int j = 0; j < 4; j++) { r.q[j] = o[1 + j]; r.s[j] = o[5 + j]; }
+            }
+        HIPCHK(hipMemcpyAsync(ctx->recs.as<HopRec>() + d.rec_base, pre.data(), pre.size() * sizeof(HopRec),
+                              hipMemcpyHostToDevice, st));
+    }
+    launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->items_d.as<WorkItem>() + ctx->comb_off,
+                       static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), st);
+    int rc = run_gating(ctx, g, false);
+    if (rc) return rc;
+    std::vector<uint32_t> hist(kEbuBins);
+    TrackOut o{};
+    unsigned long long pk[kMaxCh];
+    HIPCHK(hipMemcpyAsync(hist.data(), ctx->hist.p, kEbuBins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(pk, ctx->peaks.p, sizeof pk, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::memset(partial, 0, sizeof *partial);
+    const int nb = ctx->cfg.gate_mode == HR_GATE_LOUDNORM ? kLnBins : kEbuBins;
+    for (int i = 0; i < nb; i++) partial->hist[i] = hist[i];
+    partial->sum_kept = o.sum_kept;
+    partial->n_kept = o.n_kept;
+    partial->n_blocks = o.n_blocks;
+    for (int c = 0; c < C; c++) std::memcpy(&partial->peak_per_ch[c], &pk[c], sizeof(double));
+    ctx->shard_open = false;
+    return HR_OK;
+}
+
+int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_result *out)
+{
+    if (!ctx || !red || !out || channels < 1 || channels > HR_MAX_CH) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> hist(kEbuBins);
+    for (int i = 0; i < kEbuBins; i++) {
+        if (red->hist[i] > 0xffffffffull) return HR_ERR_TOO_LARGE;
+        hist[i] = static_cast<uint32_t>(red->hist[i]);
+    }
+    TrackOut o{};
+    o.sum_kept = red->sum_kept;
+    o.n_kept = red->n_kept;
+    o.n_blocks = red->n_blocks;
+    TrackDesc d{};  // k_gate_final only reads n_blocks/blk_base in HR_GATE_EXACT
+    int rc = upload(ctx->hist, hist.data(), kEbuBins * sizeof(uint32_t), st);
+    if (!rc) rc = upload(ctx->outs, &o, sizeof o, st);
+    if (!rc) rc = upload(ctx->tracks_d, &d, sizeof d, st);
+    if (rc) return rc;
+    if (!ctx->blk_powers.ensure(sizeof(double))) return HR_ERR_OOM;
+    launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(),
+                      ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(),
+                      ctx->ln_bounds.as<double>(), ctx->outs.as<TrackOut>(), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    unsigned long long pk[kMaxCh] = {0};
+    for (int c = 0; c < channels; c++) std::memcpy(&pk[c], &red->peak_per_ch[c], sizeof(double));
+    std::memset(out, 0, sizeof *out);
+    fill_result(ctx, o, pk, channels, out);
+    return HR_OK;
+}
+
+int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_rate, uint32_t channels, uint64_t frames)
+{
+    if (!ctx || !device_pcm || channels < 1 || channels > HR_MAX_CH || sample_rate < 10) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    SynthPar p;
+    synth_params(seed, sample_rate, frames, &p);
+    launch_synth(static_cast<float *>(device_pcm), seed, p, channels, frames, ctx->stream);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return HR_OK;
+}
+
+int hr_last_timing(hr_ctx *ctx, float *total_ms, float *main_kernel_ms)
+{
+    if (!ctx) return HR_ERR_INVALID;
+    if (total_ms) *total_ms = ctx->last_total_ms;
+    if (main_kernel_ms) *main_kernel_ms = ctx->last_main_ms;
+    return HR_OK;
+}
+
+const char *hr_strerror(int code)
+{
+    switch (code) {
+    case HR_OK: return "ok";
+    case HR_ERR_INVALID: return "invalid argument";
+    case HR_ERR_NO_DEVICE: return "no HIP device found (the meter has no CPU fallback)";
+    case HR_ERR_HIP: return "HIP runtime error";
+    case HR_ERR_OOM: return "out of device or pinned memory";
+    case HR_ERR_RATE: return "sample rate not supported by the selected true-peak mode";
+    case HR_ERR_FORMAT: return "unsupported sample format or channel count";
+    case HR_ERR_TOO_LARGE: return "input exceeds the entry point's limit";
+    default: return "unknown error";
+    }
+}
+
+}  // extern "C"

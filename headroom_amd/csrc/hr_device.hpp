@@ -1,0 +1,73 @@
+// hr_device.hpp -- structures shared by the host driver (hr_api.hip) and the kernels.
+#pragma once
+
+#include <cstdint>
+
+#include "hr_tables.hpp"
+
+namespace hr {
+
+constexpr int kPreRec = 6;   // hop records kept in front of hop 0 (left shard edge; zeros otherwise)
+constexpr int kPreHop = 3;   // hop sums kept in front of hop 0 (complete the 3 boundary blocks)
+constexpr int kHalo = 16;    // frames of FIR halo on each side of a shard
+constexpr int kEbuBins = 8001;
+constexpr int kLnBins = 1000;
+
+// per sample rate, device resident
+struct RateDev {
+    KCoef k;
+    double G[16];
+    double M1[16], M2[16];
+    const double *g;         // [hop][4]
+    const double *swr_taps;  // [(phases+1)][32] f64
+    const float *swr_taps32; // same, f32 (screen kernels)
+    uint32_t hop;
+    int32_t swr_phases, swr_step;
+    double swr_l1;
+};
+
+// zero-state record of one (hop, channel)
+struct HopRec {
+    double e0;    // sum z0^2
+    double q[4];  // sum z0[n]*g[n][j]
+    double s[4];  // zero-state end state (y1, y1-y2, z1, z1-z2)
+};
+
+struct TrackDesc {
+    const void *pcm;  // device pointer, interleaved
+    uint64_t frames;
+    uint64_t n_hops;
+    uint64_t rec_base;  // HopRec index of this track's first slot; (hop h, ch c) is rec_base + (kPreRec + h)*ch + c
+    uint64_t hop_base;  // hop-sum index of the first slot; (hop h, ch c) is hop_base + (kPreHop + h)*ch + c
+    uint64_t blk_base;  // first block-power slot
+    int64_t blk_first;  // first block index: 0, or -3 for a shard that has a left neighbour
+    uint64_t n_blocks;
+    const double *left_tail;   // [kHalo][ch] frames before frame 0 (shards), or nullptr
+    const double *right_head;  // [kHalo][ch] frames after the last frame (shards), or nullptr
+    uint32_t fs, hop;
+    int32_t rate_idx;
+    uint16_t ch, fmt;
+    uint8_t stream_start;  // frame 0 is the start of the stream (swr start reflection / zero history)
+    uint8_t stream_end;    // last frame is the end of the stream (no resampler flush: last 16 positions dropped)
+    uint8_t tp_enabled;    // resampler produces output at all (stream >= 33 frames)
+    uint8_t pad;
+    float w[kMaxCh];
+};
+
+// one workgroup's share of a launch
+struct WorkItem {
+    uint32_t track;
+    uint32_t pad;
+    uint64_t first;  // first hop (K-weight kernels) or first frame (true-peak kernels)
+};
+
+struct TrackOut {  // what the finalize kernel hands to the host
+    double mean_energy;  // gated mean block energy (0 when nothing passed)
+    double rel_energy;   // mean energy of the abs-gated blocks (before the -10 LU)
+    double sum_kept;
+    uint64_t n_kept;
+    uint64_t n_gated_final;  // blocks in the final integration
+    uint64_t n_blocks;
+};
+
+}  // namespace hr

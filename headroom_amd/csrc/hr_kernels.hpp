@@ -1,0 +1,36 @@
+// hr_kernels.hpp -- launchers implemented in the .hip files.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "hr_device.hpp"
+
+namespace hr {
+
+// hr_kernels_generic.hip
+void launch_hop_zero_state(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
+                           uint32_t n_items, HopRec *recs, hipStream_t st);
+void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
+                        const HopRec *recs, double *hop_sums, hipStream_t st);
+void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
+                       const double *ln_bounds, double *block_powers, uint32_t *hist, TrackOut *outs, hipStream_t st);
+void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
+                       const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
+                       const double *ln_bounds, TrackOut *outs, hipStream_t st);
+// tp_kind: 0 swr192k, 1 bs1770, 2 sample peak
+void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
+                              const double *bs_taps, const WorkItem *items, uint32_t n_items,
+                              unsigned long long *peaks, hipStream_t st);
+
+// hr_synth.hip
+struct SynthPar {
+    float a_noise, a_sine, burst;
+    uint32_t sine_step;
+    uint64_t quiet_len;
+    uint64_t burst_pos[3];
+    uint32_t burst_len;
+};
+void synth_params(uint64_t seed, uint32_t fs, uint64_t frames, SynthPar *p);
+void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channels, uint64_t frames, hipStream_t st);
+
+}  // namespace hr

@@ -1,0 +1,517 @@
+// hr_kernels_generic.hip -- format-agnostic f64 kernels of the meter (any sample format, 1..8
+// channels, any supported rate).  They define the arithmetic of the GPU path; the fused f32
+// kernels in hr_kernels_fused.hip are checked against them and against the oracle.
+//
+//   k_hop_zero_state   K1+K2a: K-weighting of every hop from zero state, in parallel, recording the
+//                      energy, the four correction dot products and the end state (HopRec)
+//   k_hop_combine      carry hand-off: true hop-start state from the previous hops' end states,
+//                      true hop energy  H = e0 + 2 s.q + s'Gs
+//   k_block_hist       K2b pass 1: 400 ms block powers, absolute gate, loudness histogram
+//   k_gate_final       K2b pass 2: relative gate and gated mean from the histogram
+//   k_true_peak_*      K3: polyphase interpolation + max |.| per channel, f64, oracle tap order
+//
+// Replaces (FFmpeg, reached from src/analyzer.rs:253-267): f_ebur128.c FILTER()/i400/gate_update,
+// swr_convert->192 kHz + fabs max; see SURVEY.md Appendix A.
+#include <hip/hip_runtime.h>
+
+#include "hr_device.hpp"
+#include "hr_kernels.hpp"
+
+namespace hr {
+
+// ---------------------------------------------------------------------------------------------
+// sample access
+// ---------------------------------------------------------------------------------------------
+template <int FMT>
+__device__ __forceinline__ double ld_sample(const void *p, uint64_t i)
+{
+    if constexpr (FMT == 0) return static_cast<double>(static_cast<const float *>(p)[i]);
+    else if constexpr (FMT == 1) return static_cast<double>(static_cast<const int16_t *>(p)[i]) * (1.0 / 32768.0);
+    else if constexpr (FMT == 2) {
+        const uint8_t *b = static_cast<const uint8_t *>(p) + 3 * i;
+        const int32_t v = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 8 | static_cast<uint32_t>(b[1]) << 16 |
+                                               static_cast<uint32_t>(b[2]) << 24);
+        return static_cast<double>(v) * (1.0 / 2147483648.0);
+    } else if constexpr (FMT == 3) return static_cast<double>(static_cast<const int32_t *>(p)[i]) * (1.0 / 2147483648.0);
+    else return static_cast<const double *>(p)[i];
+}
+
+// frame i of channel c with the shard halos; reflect = libswresample's start reflection x[-k] = x[k]
+template <int FMT>
+__device__ __forceinline__ double fetch(const TrackDesc &t, int c, int64_t i, bool reflect)
+{
+    const int64_t N = static_cast<int64_t>(t.frames);
+    if (i < 0) {
+        if (t.left_tail) return (i >= -kHalo) ? t.left_tail[(kHalo + i) * t.ch + c] : 0.0;
+        if (!reflect) return 0.0;
+        i = -i;
+    }
+    if (i >= N) {
+        if (t.right_head && i - N < kHalo) return t.right_head[(i - N) * t.ch + c];
+        return 0.0;
+    }
+    return ld_sample<FMT>(t.pcm, static_cast<uint64_t>(i) * t.ch + c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// K1 + K2a: every hop from zero state
+// ---------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ void __launch_bounds__(256) k_hop_zero_state(const TrackDesc *__restrict__ tracks,
+                                                        const RateDev *__restrict__ rates,
+                                                        const WorkItem *__restrict__ items,
+                                                        HopRec *__restrict__ recs)
+{
+    const WorkItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    const uint64_t h = it.first + threadIdx.x;
+    if (h >= t.n_hops) return;
+    const RateDev &r = rates[t.rate_idx];
+    const KCoef k = r.k;
+    const int C = t.ch;
+    const uint32_t L = t.hop;
+    const int64_t n0 = static_cast<int64_t>(h) * L;
+    const double *__restrict__ g = r.g;
+
+    for (int c = 0; c < C; c++) {
+        // input history is data, not state: take it from the samples in front of the hop
+        double x1 = (n0 >= 1 || t.left_tail) ? fetch<FMT>(t, c, n0 - 1, false) : 0.0;
+        double x2 = (n0 >= 2 || t.left_tail) ? fetch<FMT>(t, c, n0 - 2, false) : 0.0;
+        double y1 = 0, y2 = 0, z1 = 0, z2 = 0, e0 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+        const uint64_t base = static_cast<uint64_t>(n0) * C + c;
+        for (uint32_t i = 0; i < L; i++) {
+            const double x0 = ld_sample<FMT>(t.pcm, base + static_cast<uint64_t>(i) * C);
+            double tt = k.pb0 * x0;
+            tt = fma(k.pb1, x1, tt);
+            tt = fma(k.pb2, x2, tt);
+            tt = fma(-k.pa2, y2, tt);
+            const double y0 = fma(-k.pa1, y1, tt);
+            double v = fma(-2.0, y1, y0);
+            v = v + y2;
+            v = fma(-k.ra2, z2, v);
+            const double z0 = fma(-k.ra1, z1, v);
+            e0 = fma(z0, z0, e0);
+            q0 = fma(z0, g[i * 4 + 0], q0);
+            q1 = fma(z0, g[i * 4 + 1], q1);
+            q2 = fma(z0, g[i * 4 + 2], q2);
+            q3 = fma(z0, g[i * 4 + 3], q3);
+            x2 = x1; x1 = x0;
+            y2 = y1; y1 = y0;
+            z2 = z1; z1 = z0;
+        }
+        HopRec &o = recs[t.rec_base + (kPreRec + h) * C + c];
+        o.e0 = e0;
+        o.q[0] = q0; o.q[1] = q1; o.q[2] = q2; o.q[3] = q3;
+        o.s[0] = y1; o.s[1] = y1 - y2; o.s[2] = z1; o.s[3] = z1 - z2;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// carry hand-off + true hop energies.  One thread per (hop, channel), hops -kPreHop .. n_hops-1.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict__ tracks,
+                                                     const RateDev *__restrict__ rates,
+                                                     const WorkItem *__restrict__ items,
+                                                     const HopRec *__restrict__ recs, double *__restrict__ hop_sums)
+{
+    const WorkItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    const int C = t.ch;
+    // it.first counts (hop, channel) pairs from the first hop to combine: hop 0, or hop -kPreHop for a
+    // shard with a left neighbour (their sums complete the boundary blocks)
+    const int pre = t.blk_first < 0 ? kPreHop : 0;
+    const uint64_t pair = it.first + threadIdx.x;
+    const uint64_t total = (t.n_hops + pre) * C;
+    if (pair >= total) return;
+    const int64_t h = static_cast<int64_t>(pair / C) - pre;
+    const int c = static_cast<int>(pair % C);
+    const RateDev &r = rates[t.rate_idx];
+
+    const HopRec *base = recs + t.rec_base + kPreRec * C + c;  // hop 0, channel c; stride C
+    const HopRec &me = base[h * C];
+    // records in front of hop 0 exist only for a shard with a left neighbour (blk_first < 0)
+    const bool edge = t.blk_first < 0;
+    const double zero4[4] = {0, 0, 0, 0};
+    const double *p1 = (h - 1 >= 0 || edge) ? base[(h - 1) * C].s : zero4;
+    const double *p2 = (h - 2 >= 0 || edge) ? base[(h - 2) * C].s : zero4;
+    const double *p3 = (h - 3 >= 0 || edge) ? base[(h - 3) * C].s : zero4;
+    double s[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        double a = p1[i];
+#pragma unroll
+        for (int j = 0; j < 4; j++) a = fma(r.M1[i * 4 + j], p2[j], a);
+#pragma unroll
+        for (int j = 0; j < 4; j++) a = fma(r.M2[i * 4 + j], p3[j], a);
+        s[i] = a;
+    }
+    double lin = 0, quad = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        lin = fma(s[i], me.q[i], lin);
+        double gs = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) gs = fma(r.G[i * 4 + j], s[j], gs);
+        quad = fma(s[i], gs, quad);
+    }
+    double H = me.e0 + (2.0 * lin + quad);
+    if (H < 0) H = 0;  // cancellation on (near-)DC input can leave a tiny negative
+    hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b pass 1: block powers, absolute gate, histogram.  One workgroup per track.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_sum(double v, double *sh)
+{
+    // fixed-order tree: bit-reproducible from run to run
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__device__ __forceinline__ unsigned long long block_reduce_sum_u64(unsigned long long v, unsigned long long *sh)
+{
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] += sh[tid + s];
+        __syncthreads();
+    }
+    const unsigned long long r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, int gate_mode,
+                                                    const double *__restrict__ hop_sums,
+                                                    const double *__restrict__ ln_bounds,
+                                                    double *__restrict__ block_powers,
+                                                    uint32_t *__restrict__ hist, TrackOut *__restrict__ outs)
+{
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    const TrackDesc &t = tracks[blockIdx.x];
+    const int C = t.ch;
+    const int nbins = gate_mode == 2 ? kLnBins : kEbuBins;
+    uint32_t *hg = hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hg[i] = 0;
+    __syncthreads();
+
+    const double bins = gate_mode == 2 ? static_cast<double>(4 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
+                                       : static_cast<double>(static_cast<uint64_t>(t.fs) * 4 / 10);
+    const double abs_exact = exp10((-70.0 + 0.691) / 10.0);  // only for HR_GATE_EXACT
+    double sum_kept = 0.0;
+    unsigned long long n_kept = 0;
+    const double *H = hop_sums + t.hop_base + kPreHop * C;
+    for (uint64_t jj = threadIdx.x; jj < t.n_blocks; jj += blockDim.x) {
+        const int64_t j = t.blk_first + static_cast<int64_t>(jj);
+        double power = gate_mode == 2 ? 0.0 : 1e-12;
+        for (int c = 0; c < C; c++) {
+            if (t.w[c] == 0.0f) continue;
+            const double s = ((H[j * C + c] + H[(j + 1) * C + c]) + H[(j + 2) * C + c]) + H[(j + 3) * C + c];
+            power += static_cast<double>(t.w[c]) * s;
+        }
+        power /= bins;
+        block_powers[t.blk_base + jj] = power;
+        if (gate_mode == 0) {
+            const double loud = -0.691 + 10.0 * log10(power);
+            if (loud >= -70.0) {
+                int b = static_cast<int>((loud - (-70.0)) * 100);
+                b = b < 0 ? 0 : (b > kEbuBins - 1 ? kEbuBins - 1 : b);
+                atomicAdd(&hg[b], 1u);
+                sum_kept += power;
+                n_kept++;
+            }
+        } else if (gate_mode == 2) {
+            if (power >= ln_bounds[0]) {
+                int lo = 0, hi = kLnBins;
+                do {
+                    const int mid = (lo + hi) / 2;
+                    if (power >= ln_bounds[mid]) lo = mid; else hi = mid;
+                } while (hi - lo != 1);
+                atomicAdd(&hg[lo], 1u);
+                sum_kept += power;
+                n_kept++;
+            }
+        } else {
+            if (power > abs_exact) { sum_kept += power; n_kept++; }
+        }
+    }
+    const double sk = block_reduce_sum(sum_kept, shd);
+    const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
+    if (threadIdx.x == 0) {
+        TrackOut &o = outs[blockIdx.x];
+        o.sum_kept = sk;
+        o.n_kept = nk;
+        o.n_blocks = t.n_blocks;
+        o.mean_energy = 0;
+        o.rel_energy = 0;
+        o.n_gated_final = 0;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2b pass 2: relative gate + gated mean.  One workgroup per track; `outs` carries sum_kept/n_kept
+// (of this track, or all-reduced over shards) and `hist` the (reduced) histogram.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict__ tracks, int gate_mode,
+                                                    const double *__restrict__ block_powers,
+                                                    const uint32_t *__restrict__ hist,
+                                                    const double *__restrict__ ebu_energy,
+                                                    const double *__restrict__ ln_energy,
+                                                    const double *__restrict__ ln_bounds,
+                                                    TrackOut *__restrict__ outs)
+{
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    const TrackDesc &t = tracks[blockIdx.x];
+    TrackOut &o = outs[blockIdx.x];
+    const uint32_t *hg = hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
+    const unsigned long long n_kept = o.n_kept;
+    if (n_kept == 0) return;  // uniform across the block
+
+    if (gate_mode == 0) {
+        double rt = o.sum_kept / static_cast<double>(n_kept);
+        if (!rt) rt = 1e-12;
+        const double rel_thr = (-0.691 + 10.0 * log10(rt)) + (-10.0);
+        int gp = static_cast<int>((rel_thr - (-70.0)) * 100);
+        gp = gp < 0 ? 0 : (gp > kEbuBins - 1 ? kEbuBins - 1 : gp);
+        double isum = 0;
+        unsigned long long nint = 0;
+        for (int i = gp + threadIdx.x; i < kEbuBins; i += blockDim.x) {
+            const unsigned cnt = hg[i];
+            nint += cnt;
+            isum += static_cast<double>(cnt) * ebu_energy[i];
+        }
+        const double is = block_reduce_sum(isum, shd);
+        const unsigned long long ni = block_reduce_sum_u64(nint, shu);
+        if (threadIdx.x == 0) {
+            o.rel_energy = rt;
+            o.n_gated_final = ni;
+            o.mean_energy = ni ? is / static_cast<double>(ni) : 0.0;
+        }
+    } else if (gate_mode == 2) {
+        double gs = 0;
+        unsigned long long above = 0;
+        for (int i = threadIdx.x; i < kLnBins; i += blockDim.x) {
+            const unsigned cnt = hg[i];
+            above += cnt;
+            gs += static_cast<double>(cnt) * ln_energy[i];
+        }
+        const double g1 = block_reduce_sum(gs, shd);
+        const unsigned long long a1 = block_reduce_sum_u64(above, shu);
+        if (a1 == 0) return;
+        const double mean1 = g1 / static_cast<double>(a1);
+        const double rel = mean1 * 0.1;
+        int start;
+        if (rel < ln_bounds[0]) start = 0;
+        else {
+            int lo = 0, hi = kLnBins;
+            do {
+                const int mid = (lo + hi) / 2;
+                if (rel >= ln_bounds[mid]) lo = mid; else hi = mid;
+            } while (hi - lo != 1);
+            start = lo;
+            if (rel > ln_energy[start]) ++start;
+        }
+        gs = 0;
+        above = 0;
+        for (int i = start + threadIdx.x; i < kLnBins; i += blockDim.x) {
+            const unsigned cnt = hg[i];
+            above += cnt;
+            gs += static_cast<double>(cnt) * ln_energy[i];
+        }
+        const double g2 = block_reduce_sum(gs, shd);
+        const unsigned long long a2 = block_reduce_sum_u64(above, shu);
+        if (threadIdx.x == 0) {
+            o.rel_energy = mean1;
+            o.n_gated_final = a2;
+            o.mean_energy = a2 ? g2 / static_cast<double>(a2) : 0.0;
+        }
+    } else {
+        const double abs_exact = exp10((-70.0 + 0.691) / 10.0);
+        const double mean1 = o.sum_kept / static_cast<double>(n_kept);
+        const double rel = 0.1 * mean1;
+        double s2 = 0;
+        unsigned long long n2 = 0;
+        for (uint64_t jj = threadIdx.x; jj < t.n_blocks; jj += blockDim.x) {
+            const double p = block_powers[t.blk_base + jj];
+            if (p > abs_exact && p > rel) { s2 += p; n2++; }
+        }
+        const double ss = block_reduce_sum(s2, shd);
+        const unsigned long long nn = block_reduce_sum_u64(n2, shu);
+        if (threadIdx.x == 0) {
+            o.rel_energy = mean1;
+            o.n_gated_final = nn;
+            o.mean_energy = nn ? ss / static_cast<double>(nn) : 0.0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: true peak, generic f64.  One thread per input position; per-channel max via atomicMax on the
+// bit pattern (non-negative doubles order like unsigned integers).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void peak_commit(double m, unsigned long long *slot)
+{
+    // wave max, then one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_down(m, off, 64);
+        m = o > m ? o : m;
+    }
+    if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(slot, static_cast<unsigned long long>(__double_as_longlong(m)));
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restrict__ tracks,
+                                                       const RateDev *__restrict__ rates,
+                                                       const WorkItem *__restrict__ items,
+                                                       unsigned long long *__restrict__ peaks)
+{
+    const WorkItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    const RateDev &r = rates[t.rate_idx];
+    const int64_t N = static_cast<int64_t>(t.frames);
+    const int64_t pos = static_cast<int64_t>(it.first) + threadIdx.x;
+    const int P = r.swr_phases, step = r.swr_step;
+    // an output at position pos needs frames pos-15 .. pos+16
+    const int64_t last_pos = t.stream_end ? N - 17 : N - 1;
+    const bool active = t.tp_enabled && pos <= last_pos && pos < N;
+    const int C = t.ch;
+    for (int c = 0; c < C; c++) {
+        double m = 0.0;
+        if (active) {
+            double x[kSwrTaps];
+#pragma unroll
+            for (int i = 0; i < kSwrTaps; i++) x[i] = fetch<FMT>(t, c, pos - 15 + i, true);
+            // outputs n with floor(n*step/P) == pos
+            const int64_t n_lo = (pos * P + step - 1) / step;
+            const int64_t n_hi = ((pos + 1) * P + step - 1) / step;
+            for (int64_t n = n_lo; n < n_hi; n++) {
+                const int ph = static_cast<int>(n * step - pos * P);
+                const double *__restrict__ f = r.swr_taps + static_cast<size_t>(ph) * kSwrTaps;
+                double val = 0.0;
+#pragma unroll
+                for (int i = 0; i < kSwrTaps; i++) val = fma(x[i], f[i], val);
+                const double a = fabs(val);
+                m = a > m ? a : m;
+            }
+        }
+        peak_commit(m, &peaks[static_cast<size_t>(it.track) * kMaxCh + c]);
+    }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256) k_true_peak_bs1770(const TrackDesc *__restrict__ tracks,
+                                                          const double *__restrict__ taps /*[4][12]*/,
+                                                          const WorkItem *__restrict__ items,
+                                                          unsigned long long *__restrict__ peaks)
+{
+    const WorkItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    const int64_t N = static_cast<int64_t>(t.frames);
+    const int64_t n = static_cast<int64_t>(it.first) + threadIdx.x;
+    const int stride = t.fs < 96000 ? 1 : 2;  // x4 below 96 kHz, x2 below 192 kHz
+    const int C = t.ch;
+    for (int c = 0; c < C; c++) {
+        double m = 0.0;
+        if (n < N) {
+            double x[12];
+#pragma unroll
+            for (int k = 0; k < 12; k++) x[k] = fetch<FMT>(t, c, n - k, false);
+            for (int p = 0; p < 4; p += stride) {
+                double val = 0.0;
+#pragma unroll
+                for (int k = 0; k < 12; k++) val = fma(x[k], taps[p * 12 + k], val);
+                const double a = fabs(val);
+                m = a > m ? a : m;
+            }
+        }
+        peak_commit(m, &peaks[static_cast<size_t>(it.track) * kMaxCh + c]);
+    }
+}
+
+template <int FMT>
+__global__ void __launch_bounds__(256) k_sample_peak(const TrackDesc *__restrict__ tracks,
+                                                     const WorkItem *__restrict__ items,
+                                                     unsigned long long *__restrict__ peaks)
+{
+    const WorkItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    const int64_t N = static_cast<int64_t>(t.frames);
+    const int64_t n = static_cast<int64_t>(it.first) + threadIdx.x;
+    const int C = t.ch;
+    for (int c = 0; c < C; c++) {
+        double m = 0.0;
+        if (n < N) m = fabs(ld_sample<FMT>(t.pcm, static_cast<uint64_t>(n) * C + c));
+        peak_commit(m, &peaks[static_cast<size_t>(it.track) * kMaxCh + c]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+#define HR_FMT_DISPATCH(fmt, CALL)            \
+    switch (fmt) {                            \
+    case 0: { constexpr int F = 0; CALL; } break; \
+    case 1: { constexpr int F = 1; CALL; } break; \
+    case 2: { constexpr int F = 2; CALL; } break; \
+    case 3: { constexpr int F = 3; CALL; } break; \
+    default: { constexpr int F = 4; CALL; } break; \
+    }
+
+void launch_hop_zero_state(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
+                           uint32_t n_items, HopRec *recs, hipStream_t st)
+{
+    if (!n_items) return;
+    HR_FMT_DISPATCH(fmt, (k_hop_zero_state<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, rates, items, recs)));
+}
+
+void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
+                        const HopRec *recs, double *hop_sums, hipStream_t st)
+{
+    if (!n_items) return;
+    hipLaunchKernelGGL(k_hop_combine, dim3(n_items), dim3(256), 0, st, tracks, rates, items, recs, hop_sums);
+}
+
+void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
+                       const double *ln_bounds, double *block_powers, uint32_t *hist, TrackOut *outs, hipStream_t st)
+{
+    if (!n_tracks) return;
+    hipLaunchKernelGGL(k_block_hist, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, hop_sums, ln_bounds,
+                       block_powers, hist, outs);
+}
+
+void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
+                       const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
+                       const double *ln_bounds, TrackOut *outs, hipStream_t st)
+{
+    if (!n_tracks) return;
+    hipLaunchKernelGGL(k_gate_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, block_powers, hist,
+                       ebu_energy, ln_energy, ln_bounds, outs);
+}
+
+void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
+                              const double *bs_taps, const WorkItem *items, uint32_t n_items,
+                              unsigned long long *peaks, hipStream_t st)
+{
+    if (!n_items) return;
+    if (tp_kind == 0) {
+        HR_FMT_DISPATCH(fmt, (k_true_peak_swr<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, rates, items, peaks)));
+    } else if (tp_kind == 1) {
+        HR_FMT_DISPATCH(fmt, (k_true_peak_bs1770<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, bs_taps, items, peaks)));
+    } else {
+        HR_FMT_DISPATCH(fmt, (k_sample_peak<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, items, peaks)));
+    }
+}
+
+}  // namespace hr

@@ -1,0 +1,230 @@
+// hr_tables.cpp -- see hr_tables.hpp.
+//
+// Follows (published algorithm, FFmpeg is not in /root/reference):
+//   kweight_coeffs      libavfilter/f_ebur128.c config_audio_input(); reference call site
+//                       src/analyzer.rs:253-267
+//   swr bank            libswresample/resample.c build_filter() with the defaults of options.c
+//                       (filter_size 32, kaiser beta 9, exact_rational)
+//   histogram energies  f_ebur128.c init(); libavfilter/ebur128.c histogram_init()
+#include "hr_tables.hpp"
+
+#include <cmath>
+#include <map>
+#include <memory>
+#include <mutex>
+
+namespace hr {
+
+KCoef kweight_coeffs(double fs)
+{
+    KCoef c;
+    double f0 = 1681.974450955533;
+    const double G = 3.999843853973347;
+    double Q = 0.7071752369554196;
+    double K = std::tan(M_PI * f0 / fs);
+    const double Vh = std::pow(10.0, G / 20.0);
+    const double Vb = std::pow(Vh, 0.4996667741545416);
+    const double a0 = 1.0 + K / Q + K * K;
+    c.pb0 = (Vh + Vb * K / Q + K * K) / a0;
+    c.pb1 = 2.0 * (K * K - Vh) / a0;
+    c.pb2 = (Vh - Vb * K / Q + K * K) / a0;
+    c.pa1 = 2.0 * (K * K - 1.0) / a0;
+    c.pa2 = (1.0 - K / Q + K * K) / a0;
+    f0 = 38.13547087602444;
+    Q = 0.5003270373238773;
+    K = std::tan(M_PI * f0 / fs);
+    c.ra1 = 2.0 * (K * K - 1.0) / (1.0 + K / Q + K * K);
+    c.ra2 = (1.0 - K / Q + K * K) / (1.0 + K / Q + K * K);
+    return c;
+}
+
+void default_weights(int channels, float *w)
+{
+    for (int c = 0; c < channels; c++) w[c] = 1.0f;
+    if (channels == 6) { w[3] = 0.0f; w[4] = 1.41f; w[5] = 1.41f; }       // L R C LFE Ls Rs
+    else if (channels == 5) { w[3] = 1.41f; w[4] = 1.41f; }               // L R C Ls Rs
+    else if (channels == 4) { w[2] = 1.41f; w[3] = 1.41f; }               // L R Ls Rs
+}
+
+static double bessel_i0(double x)
+{
+    double v = 1.0, lastv = 0.0, t = 1.0;
+    const double q = x * x / 4.0;
+    for (int i = 1; v != lastv && i < 1000; i++) {
+        lastv = v;
+        t *= q / (static_cast<double>(i) * static_cast<double>(i));
+        v += t;
+    }
+    return v;
+}
+
+static uint64_t gcd_u64(uint64_t a, uint64_t b)
+{
+    while (b) { const uint64_t t = a % b; a = b; b = t; }
+    return a;
+}
+
+static void build_swr(RateTables &rt)
+{
+    const uint32_t out_rate = 192000;
+    if (rt.fs >= out_rate) return;
+    const uint64_t g = gcd_u64(rt.fs, out_rate);
+    const int P = static_cast<int>(out_rate / g);
+    if (P > 1024) { rt.swr_phases = -1; return; }  // libswresample would interpolate between phases
+    rt.swr_phases = P;
+    rt.swr_step = static_cast<int>(rt.fs / g);
+    rt.swr_taps.assign(static_cast<size_t>(P + 1) * kSwrTaps, 0.0);
+    const int center = (kSwrTaps - 1) / 2;
+    const int ph_nb = P % 2 ? P : P / 2 + 1;
+    double norm = 0.0, tab[kSwrTaps];
+    double *taps = rt.swr_taps.data();
+    for (int ph = 0; ph < ph_nb; ph++) {
+        double s = std::sin(M_PI * ph / P) * (center & 1 ? 1 : -1);
+        for (int i = 0; i < kSwrTaps; i++) {
+            const double x = M_PI * (static_cast<double>(i - center) - static_cast<double>(ph) / P);
+            double y = x == 0 ? 1.0 : s / x;
+            const double w = 2.0 * x / (kSwrTaps * M_PI);
+            y *= bessel_i0(9.0 * std::sqrt(std::fmax(1 - w * w, 0)));
+            tab[i] = y;
+            s = -s;
+            if (!ph) norm += y;
+        }
+        for (int i = 0; i < kSwrTaps; i++) taps[ph * kSwrTaps + i] = tab[i] / norm;
+        if (P % 2) continue;
+        for (int i = 0; i < kSwrTaps; i++)
+            taps[(P - ph) * kSwrTaps + kSwrTaps - 1 - i] = taps[ph * kSwrTaps + i];
+    }
+    if (P % 2)
+        for (int i = 0; i < kSwrTaps; i++) taps[P * kSwrTaps + i] = i ? taps[i - 1] : 0.0;
+    for (int ph = 0; ph < P; ph++) {
+        double l1 = 0;
+        for (int i = 0; i < kSwrTaps; i++) l1 += std::fabs(taps[ph * kSwrTaps + i]);
+        if (l1 > rt.swr_l1) rt.swr_l1 = l1;
+    }
+}
+
+static void matmul4(const long double *a, const long double *b, long double *c)
+{
+    for (int i = 0; i < 4; i++)
+        for (int j = 0; j < 4; j++) {
+            long double s = 0;
+            for (int k = 0; k < 4; k++) s += a[i * 4 + k] * b[k * 4 + j];
+            c[i * 4 + j] = s;
+        }
+}
+
+static void build_carry(RateTables &rt)
+{
+    const uint32_t L = rt.hop;
+    const KCoef &k = rt.k;
+    rt.g.assign(static_cast<size_t>(L) * 4, 0.0);
+    long double G[16] = {0}, M[16];
+    std::vector<long double> gl(static_cast<size_t>(L) * 4);
+    for (int j = 0; j < 4; j++) {
+        // unit component j of the hop-start state s = (y[-1], y[-1]-y[-2], z[-1], z[-1]-z[-2]) (value and
+        // backward difference: far better conditioned than raw histories, whose responses nearly cancel);
+        // input history zero
+        long double y1 = j == 0, y2 = (j == 0) - (j == 1), z1 = j == 2, z2 = (j == 2) - (j == 3);
+        for (uint32_t n = 0; n < L; n++) {
+            const long double y0 = -static_cast<long double>(k.pa1) * y1 - static_cast<long double>(k.pa2) * y2;
+            const long double z0 = (y0 - 2.0L * y1 + y2) - static_cast<long double>(k.ra1) * z1 -
+                                   static_cast<long double>(k.ra2) * z2;
+            gl[static_cast<size_t>(n) * 4 + j] = z0;
+            y2 = y1; y1 = y0;
+            z2 = z1; z1 = z0;
+        }
+        M[0 * 4 + j] = y1; M[1 * 4 + j] = y1 - y2; M[2 * 4 + j] = z1; M[3 * 4 + j] = z1 - z2;
+    }
+    for (uint32_t n = 0; n < L; n++)
+        for (int a = 0; a < 4; a++) {
+            rt.g[static_cast<size_t>(n) * 4 + a] = static_cast<double>(gl[static_cast<size_t>(n) * 4 + a]);
+            for (int b = 0; b < 4; b++) G[a * 4 + b] += gl[static_cast<size_t>(n) * 4 + a] * gl[static_cast<size_t>(n) * 4 + b];
+        }
+    for (int i = 0; i < 16; i++) rt.G[i] = static_cast<double>(G[i]);
+    long double Mp[16], Mn[16];
+    for (int i = 0; i < 16; i++) { Mp[i] = M[i]; rt.M[0][i] = static_cast<double>(M[i]); }
+    for (int t = 1; t < kCarryTerms; t++) {
+        matmul4(Mp, M, Mn);
+        for (int i = 0; i < 16; i++) {
+            Mp[i] = Mn[i];
+            if (t < kCarryTerms - 1) rt.M[t][i] = static_cast<double>(Mn[i]);
+        }
+    }
+    long double r = 0;
+    for (int i = 0; i < 16; i++) r = std::fmax(r, std::fabs(Mp[i]));
+    rt.carry_residual = static_cast<double>(r);
+}
+
+const RateTables *rate_tables(uint32_t fs)
+{
+    static std::mutex mu;
+    static std::map<uint32_t, std::unique_ptr<RateTables>> cache;
+    if (fs < 10) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    auto it = cache.find(fs);
+    if (it != cache.end()) return it->second.get();
+    auto rt = std::make_unique<RateTables>();
+    rt->fs = fs;
+    rt->hop = fs / 10;
+    rt->k = kweight_coeffs(static_cast<double>(fs));
+    build_carry(*rt);
+    build_swr(*rt);
+    const RateTables *p = rt.get();
+    cache[fs] = std::move(rt);
+    return p;
+}
+
+const double *bs1770_taps()
+{
+    static const double t[4][12] = {
+        {0.0017089843750, 0.0109863281250, -0.0196533203125, 0.0332031250000, -0.0594482421875,
+         0.1373291015625, 0.9721679687500, -0.1022949218750, 0.0476074218750, -0.0266113281250,
+         0.0148925781250, -0.0083007812500},
+        {-0.0291748046875, 0.0292968750000, -0.0517578125000, 0.0891113281250, -0.1665039062500,
+         0.4650878906250, 0.7797851562500, -0.2003173828125, 0.1015625000000, -0.0582275390625,
+         0.0330810546875, -0.0189208984375},
+        {-0.0189208984375, 0.0330810546875, -0.0582275390625, 0.1015625000000, -0.2003173828125,
+         0.7797851562500, 0.4650878906250, -0.1665039062500, 0.0891113281250, -0.0517578125000,
+         0.0292968750000, -0.0291748046875},
+        {-0.0083007812500, 0.0148925781250, -0.0266113281250, 0.0476074218750, -0.1022949218750,
+         0.9721679687500, 0.1373291015625, -0.0594482421875, 0.0332031250000, -0.0196533203125,
+         0.0109863281250, 0.0017089843750},
+    };
+    return &t[0][0];
+}
+
+const std::vector<double> &ebur128_bin_energy()
+{
+    static const std::vector<double> v = [] {
+        std::vector<double> e(8001);
+        for (int i = 0; i < 8001; i++) {
+            const double loud = static_cast<double>(i) / 100.0 + (-70.0);
+            e[i] = std::pow(10.0, (loud + 0.691) / 10.0);
+        }
+        return e;
+    }();
+    return v;
+}
+
+const std::vector<double> &loudnorm_bin_energy()
+{
+    static const std::vector<double> v = [] {
+        std::vector<double> e(1000);
+        for (int i = 0; i < 1000; ++i) e[i] = std::pow(10.0, (static_cast<double>(i) / 10.0 - 69.95 + 0.691) / 10.0);
+        return e;
+    }();
+    return v;
+}
+
+const std::vector<double> &loudnorm_bin_bounds()
+{
+    static const std::vector<double> v = [] {
+        std::vector<double> e(1001);
+        e[0] = std::pow(10.0, (-70.0 + 0.691) / 10.0);
+        for (int i = 1; i < 1001; ++i) e[i] = std::pow(10.0, (static_cast<double>(i) / 10.0 - 70.0 + 0.691) / 10.0);
+        return e;
+    }();
+    return v;
+}
+
+}  // namespace hr

@@ -1,0 +1,53 @@
+// hr_tables.hpp -- host-side constant tables of the meter (K-weighting coefficients, the
+// zero-input-response tables that let every hop be filtered independently, resampler banks,
+// gating histogram energies).  Product code: shares nothing with oracle/.
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+namespace hr {
+
+constexpr int kMaxCh = 8;
+constexpr int kSwrTaps = 32;
+constexpr int kCarryTerms = 3;  // s_in = zend[h-1] + M zend[h-2] + M^2 zend[h-3]
+
+// K-weighting, FFmpeg f_ebur128.c config_audio_input parametrisation
+struct KCoef {
+    double pb0, pb1, pb2, pa1, pa2;  // pre-filter (high shelf)
+    double ra1, ra2;                 // RLB high-pass, b = {1,-2,1}
+};
+KCoef kweight_coeffs(double fs);
+
+// Everything a kernel needs to know about one sample rate.
+struct RateTables {
+    uint32_t fs = 0;
+    uint32_t hop = 0;  // fs/10
+    KCoef k{};
+    // zero-input response of the cascade: the K-weighted output at offset n of a hop is
+    //   z[n] = z0[n] + sum_j s[j]*g[n][j],  s = (y[-1], y[-1]-y[-2], z[-1], z[-1]-z[-2]) at the hop start
+    std::vector<double> g;   // [hop][4]
+    double G[16];            // sum_n g[n][j]*g[n][k]
+    double M[kCarryTerms - 1][16];  // M^1, M^2 (row-major): state transfer over one hop
+    double carry_residual = 0;      // |M^kCarryTerms|_max, must be negligible
+    // libswresample bank to 192 kHz (phase_count == 0: no resampling, true peak = sample peak)
+    int swr_phases = 0, swr_step = 0;
+    std::vector<double> swr_taps;  // [(phases+1)][32]
+    double swr_l1 = 0;             // max over phases of sum |tap|
+};
+
+// Builds (and caches per process) the tables of one rate.  Returns nullptr for fs < 10.
+const RateTables *rate_tables(uint32_t fs);
+
+// BS.1770-4 Annex 2 taps, [4][12]
+const double *bs1770_taps();
+
+// f_ebur128.c histogram bin energies: ENERGY(i/100 - 70), i < 8001
+const std::vector<double> &ebur128_bin_energy();
+// libavfilter/ebur128.c tables: bin-centre energies [1000] and boundaries [1001]
+const std::vector<double> &loudnorm_bin_energy();
+const std::vector<double> &loudnorm_bin_bounds();
+
+void default_weights(int channels, float *w);
+
+}  // namespace hr

@@ -1,0 +1,200 @@
+/*
+ * headroom_hip.h -- C ABI of the MI355X-native loudness / true-peak meter.
+ *
+ * Drop-in boundary for the measurement step of M-Igashi/headroom's analyzer.  The reference has
+ * no FFI for this path: src/analyzer.rs:253-267 spawns `ffmpeg -af loudnorm=print_format=json`
+ * and src/analyzer.rs:273-280 parses `input_i` / `input_tp` out of its stderr.  A maintainer
+ * replaces that process boundary with the entry points below (the Rust `extern "C"` block is
+ * shown in INTEGRATION.md).  Plain pointers and sizes only; no exceptions cross this boundary.
+ *
+ * Library: headroom_amd/libheadroom_hip.so (hipcc --offload-arch=gfx950).
+ */
+#ifndef HEADROOM_HIP_H
+#define HEADROOM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HR_MAX_CH 8
+
+/* error codes (0 = ok, < 0 = error); also used in hr_result.status */
+enum {
+    HR_OK = 0,
+    HR_ERR_INVALID = -1,       /* NULL / malformed argument                                  */
+    HR_ERR_NO_DEVICE = -2,     /* no usable gfx950 device (analogue of check_ffmpeg failing) */
+    HR_ERR_HIP = -3,           /* a HIP runtime call failed                                  */
+    HR_ERR_OOM = -4,           /* device or pinned allocation failed                         */
+    HR_ERR_RATE = -5,          /* sample rate not supported by the selected true-peak mode   */
+    HR_ERR_FORMAT = -6,        /* unknown sample format / channel count                      */
+    HR_ERR_TOO_LARGE = -7      /* input exceeds a stated limit of the entry point            */
+};
+
+/* interleaved PCM sample formats (what ffmpeg would decode `-map 0:a:0` to) */
+enum { HR_FMT_F32 = 0, HR_FMT_S16 = 1, HR_FMT_S24 = 2 /* packed 3-byte LE */, HR_FMT_S32 = 3, HR_FMT_F64 = 4 };
+
+/* gating: which FFmpeg code path is reproduced */
+enum {
+    HR_GATE_EBUR128 = 0,  /* libavfilter/f_ebur128.c: 8001 x 0.01 LU histogram  (default)     */
+    HR_GATE_EXACT = 1,    /* ITU-R BS.1770-4 text, no histogram                               */
+    HR_GATE_LOUDNORM = 2  /* libavfilter/ebur128.c (af_loudnorm): 1000 x 0.1 LU histogram     */
+};
+
+/* true peak: which interpolator */
+enum {
+    HR_TP_SWR192K = 0, /* libswresample defaults to 192 kHz, as f_ebur128 peak=true (default) */
+    HR_TP_BS1770 = 1,  /* ITU-R BS.1770-4 Annex 2, 4 x 12-tap polyphase FIR                   */
+    HR_TP_SAMPLE = 2   /* sample peak only                                                    */
+};
+
+/* hr_track.flags */
+enum {
+    HR_TRACK_DEVICE_PCM = 1u /* pcm is a device pointer on the context's GPU (already in HBM) */
+};
+
+typedef struct hr_ctx hr_ctx;
+
+typedef struct hr_config {
+    int32_t device;     /* HIP device ordinal                                               */
+    int32_t gate_mode;  /* HR_GATE_*                                                        */
+    int32_t tp_mode;    /* HR_TP_*                                                          */
+    int32_t engine;     /* 0 = default (fastest available), 1 = force the generic kernels   */
+    void *stream;       /* hipStream_t to run on, or NULL for a stream owned by the context */
+    uint64_t stage_bytes; /* device staging for host-resident PCM; 0 = default (1 GiB)      */
+} hr_config;
+
+/* One decoded audio stream (the first audio stream of a file: `-map 0:a:0`, analyzer.rs:258). */
+typedef struct hr_track {
+    const void *pcm;        /* interleaved samples, host (pageable or pinned) or device     */
+    uint64_t frames;        /* samples per channel                                          */
+    uint32_t sample_rate;   /* Hz                                                           */
+    uint16_t channels;      /* 1..HR_MAX_CH                                                 */
+    uint16_t fmt;           /* HR_FMT_*                                                     */
+    const float *ch_weight; /* host pointer, len = channels; 0 excludes a channel from loudness
+                               (never from true peak); NULL = FFmpeg's default layout weights */
+    uint32_t flags;         /* HR_TRACK_*                                                   */
+    uint32_t reserved;
+} hr_track;
+
+/* What analyzer.rs:273-280 reads (`input_i`, `input_tp`) plus the meter's side outputs. */
+typedef struct hr_result {
+    double integrated_lufs;    /* -INFINITY when no block passes the -70 LUFS gate (silence);
+                                  the caller applies analyzer.rs:284 to reject it             */
+    double true_peak_dbtp;     /* 20*log10(max over channels); -INFINITY for digital silence  */
+    double rel_threshold_lufs; /* relative gate                                               */
+    uint64_t n_blocks;         /* 400 ms blocks                                               */
+    uint64_t n_gated;          /* blocks above the absolute gate                              */
+    double peak_per_ch[HR_MAX_CH]; /* linear true peak per channel (all channels, LFE too)    */
+    int32_t status;            /* HR_OK or the error that made this track fail                */
+    int32_t reserved;
+} hr_result;
+
+/* Replaces check_ffmpeg() (src/analyzer.rs:348-354, called at src/cli.rs:30): number of usable
+ * devices, 0 when there is none. */
+int hr_device_count(void);
+
+/* Creates the per-GPU context (device tables, workspace, stream).  HR_ERR_NO_DEVICE when the HIP
+ * runtime finds no device: the library never falls back to a CPU path. */
+int hr_init(const hr_config *cfg, hr_ctx **out);
+void hr_destroy(hr_ctx *ctx);
+
+/* Pinned host memory for decoded PCM (fast H2D). */
+void *hr_alloc_pinned(size_t bytes);
+void hr_free_pinned(void *p);
+
+/* Replaces the body of analyze_file_with_target up to the two parsed numbers
+ * (src/analyzer.rs:253-280) for a whole batch, i.e. the work of analyze_files' par_iter
+ * (src/cli.rs:403-435): results are in input order, a bad track sets out[i].status and does not
+ * fail the batch (src/cli.rs:419-430).  Thread-safe per context (serialised internally). */
+int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out);
+
+/* Debug / parity entry: per-hop K-weighted energies H[hop*channels + ch] and 400 ms block powers
+ * (f_ebur128.c power_400, 1e-12 floor included) of one track.  Either output may be NULL.
+ * No counterpart in the reference; exists for the 1e-6 block-energy parity check. */
+int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint64_t cap_hops,
+                      double *block_powers, uint64_t cap_blocks, uint64_t *n_hops, uint64_t *n_blocks);
+
+/* One time shard of a long stream (BASELINE config 5: one stream time-sharded over the GPUs of a
+ * node, one process per GPU).  The stream is cut at multiples of the hop (sample_rate/10); every
+ * shard but the last holds a whole number of hops and at least 6 of them.  Each rank runs pass1
+ * on its shard, hands its hr_shard_edge to the right neighbour, runs pass2 with the edge it got
+ * from the left, and the hr_shard_partial records are all-reduced (sum; max for the peaks) before
+ * hr_shard_finish.  HR_GATE_EXACT needs a second reduction and is not offered here.
+ * No counterpart in the reference: ffmpeg handles a file strictly sequentially. */
+typedef struct hr_shard_edge {
+    /* zero-state records of the shard's last 6 hops, oldest first, per channel:
+       {energy, 4 correction dot products, 4 end-state values} */
+    double rec[6][HR_MAX_CH][9];
+    double tail[16][HR_MAX_CH]; /* last 16 frames: FIR halo and filter input history */
+    uint64_t n_hops;
+} hr_shard_edge;
+
+typedef struct hr_shard_partial {
+    uint64_t hist[8001];   /* gating histogram counts of this shard's blocks  */
+    double sum_kept;       /* sum of block powers above the absolute gate     */
+    uint64_t n_kept;
+    uint64_t n_blocks;
+    double peak_per_ch[HR_MAX_CH];
+} hr_shard_partial;
+
+/* The first 16 frames of a shard as doubles, head[16][HR_MAX_CH]: what its left neighbour needs as
+ * right_head. */
+int hr_shard_head(hr_ctx *ctx, const hr_track *shard, double *head);
+/* Phase 1: K-weighting of every hop from zero state + true peak.  left_tail / right_head are the 16
+ * frames before / after the shard ([16][HR_MAX_CH] doubles: the left neighbour's hr_shard_edge.tail
+ * and the right neighbour's hr_shard_head; NULL at the stream's ends, is_first / is_last).  Writes
+ * this shard's right edge. */
+int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head,
+                   int is_first, int is_last, hr_shard_edge *right_edge_out);
+/* Phase 2: IIR carry hand-off from the left neighbour's edge (NULL for the first shard), the three
+ * boundary blocks, and this shard's gating partial. */
+int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left_edge, hr_shard_partial *partial_out);
+/* Gating from the all-reduced partial. */
+int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *reduced, int channels, hr_result *out);
+
+/* Deterministic synthetic PCM written straight into device memory (bench / tests):
+ * f32 interleaved, `frames` x `channels`.  Same bits as the oracle's generator. */
+int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_rate,
+                  uint32_t channels, uint64_t frames);
+
+/* Device time of the last hr_analyze_batch on this context, in milliseconds, measured with HIP
+ * events on the library's own stream: total of the compute kernels, and of the dominant (fused
+ * K-weight + true-peak) kernel alone. */
+int hr_last_timing(hr_ctx *ctx, float *total_ms, float *main_kernel_ms);
+
+const char *hr_strerror(int code);
+
+/* ---- host-side mirror of the analyzer's scalar logic (src/analyzer.rs:157-187, :304-326) ---- */
+
+enum { /* GainMethod, src/analyzer.rs:36-50 */
+    HR_GAIN_FFMPEG_LOSSLESS = 0, HR_GAIN_MP3_LOSSLESS = 1, HR_GAIN_MP3_REENCODE = 2,
+    HR_GAIN_AAC_LOSSLESS = 3, HR_GAIN_AAC_REENCODE = 4, HR_GAIN_NONE = 5
+};
+enum { HR_KIND_LOSSLESS = 0, HR_KIND_MP3 = 1, HR_KIND_AAC = 2 }; /* scanner::is_mp3 / is_aac */
+
+typedef struct hr_tp_target { /* TpTargetMode, src/analyzer.rs:157-164 */
+    int32_t split;  /* 0 = Uniform(high), 1 = SplitBitrate(high, low) */
+    double high, low;
+} hr_tp_target;
+
+typedef struct hr_analysis { /* AudioAnalysis minus the path strings, src/analyzer.rs:52-65 */
+    double input_i, input_tp;
+    int32_t has_bitrate; uint32_t bitrate_kbps;
+    double target_tp, headroom;
+    int32_t gain_method;
+    double effective_gain;
+    int32_t lossless_gain_steps;
+    int32_t status; /* HR_OK, or HR_ERR_INVALID for a non-finite measurement (analyzer.rs:284) */
+} hr_analysis;
+
+/* src/analyzer.rs:284-326 applied to one measurement. */
+int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
+                     const hr_tp_target *mode, hr_analysis *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,136 @@
+"""CPU-side tests (no GPU): the C-ABI library loads and exports every symbol include/headroom_hip.h
+declares, struct layouts match the header, the host-side mirror of the analyzer's scalar logic
+(src/analyzer.rs:157-187, :284-326) behaves like the reference, and the product's own constant tables
+agree with the oracle's."""
+import ctypes as C
+import math
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import headroom_amd as hr
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "headroom_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(hr_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(hr.EXPORTS), declared ^ set(hr.EXPORTS)
+    L = hr.lib()
+    for name in declared:
+        assert getattr(L, name) is not None
+
+
+def test_struct_sizes_match_header():
+    # compile a tiny C program against the header and compare sizeof()
+    src = r'''
+#include <stdio.h>
+#include "headroom_hip.h"
+int main(void){ printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(hr_config), sizeof(hr_track), sizeof(hr_result),
+  sizeof(hr_shard_edge), sizeof(hr_shard_partial), sizeof(hr_tp_target), sizeof(hr_analysis)); return 0; }'''
+    exe = "/tmp/hr_sizes"
+    subprocess.run(["gcc", "-x", "c", "-", "-I", os.path.join(ROOT, "include"), "-o", exe], input=src.encode(), check=True)
+    sizes = list(map(int, subprocess.check_output([exe]).split()))
+    mine = [C.sizeof(t) for t in (hr.HrConfig, hr.HrTrack, hr.HrResult, hr.HrShardEdge, hr.HrShardPartial,
+                                  hr.HrTpTarget, hr.HrAnalysis)]
+    assert sizes == mine
+
+
+def test_no_device_means_error_not_fallback():
+    if hr.device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(hr.HeadroomError) as e:
+        hr.Meter()
+    assert e.value.code == hr.ERR_NO_DEVICE
+
+
+def test_strerror():
+    assert hr.lib().hr_strerror(0) == b"ok"
+    assert b"no HIP device" in hr.lib().hr_strerror(hr.ERR_NO_DEVICE)
+
+
+# ---- gain decision: src/analyzer.rs:304-326 ---------------------------------------------------
+
+def test_gain_none_below_min_effective_gain():
+    rc, a = hr.gain_decision(-9.0, -0.52)  # headroom 0.02 < 0.05
+    assert rc == 0 and a["gain_method"] == hr.GAIN_NONE and a["effective_gain"] == 0.0
+    assert abs(a["headroom"] - 0.02) < 1e-12 and a["target_tp"] == -0.5
+
+
+def test_gain_lossless_uses_full_headroom():
+    rc, a = hr.gain_decision(-14.0, -3.2)
+    assert a["gain_method"] == hr.GAIN_FFMPEG_LOSSLESS
+    assert abs(a["effective_gain"] - 2.7) < 1e-12 and a["lossless_gain_steps"] == 0
+    assert a["has_bitrate"] == 0
+
+
+def test_gain_mp3_steps_of_1_5_db():
+    rc, a = hr.gain_decision(-12.0, -5.0, kind=hr.KIND_MP3, bitrate_kbps=320)  # headroom 4.5 -> 3 steps
+    assert a["gain_method"] == hr.GAIN_MP3_LOSSLESS and a["lossless_gain_steps"] == 3
+    assert abs(a["effective_gain"] - 4.5) < 1e-12
+    rc, a = hr.gain_decision(-12.0, -1.9, kind=hr.KIND_MP3, bitrate_kbps=320)  # headroom 1.4 -> re-encode
+    assert a["gain_method"] == hr.GAIN_MP3_REENCODE and a["lossless_gain_steps"] == 0
+    assert abs(a["effective_gain"] - 1.4) < 1e-12
+    rc, a = hr.gain_decision(-12.0, -3.6, kind=hr.KIND_AAC, bitrate_kbps=256)  # headroom 3.1 -> 2 steps
+    assert a["gain_method"] == hr.GAIN_AAC_LOSSLESS and a["lossless_gain_steps"] == 2
+    rc, a = hr.gain_decision(-12.0, -1.0, kind=hr.KIND_AAC)
+    assert a["gain_method"] == hr.GAIN_AAC_REENCODE
+
+
+def test_tp_target_split_bitrate():
+    # TpTargetMode::SplitBitrate(high, low): lossless and >= 256 kbps -> high, else (or unknown) -> low
+    for kind, kbps, want in ((hr.KIND_LOSSLESS, None, -0.5), (hr.KIND_MP3, 320, -0.5), (hr.KIND_MP3, 256, -0.5),
+                             (hr.KIND_MP3, 192, -1.0), (hr.KIND_AAC, None, -1.0)):
+        rc, a = hr.gain_decision(-10.0, -6.0, kind=kind, bitrate_kbps=kbps, split=(-0.5, -1.0))
+        assert a["target_tp"] == want, (kind, kbps)
+
+
+def test_non_finite_measurement_is_rejected():
+    # src/analyzer.rs:284-290
+    for i, tp in ((-math.inf, -3.0), (-14.0, -math.inf), (math.nan, 0.0)):
+        rc, a = hr.gain_decision(i, tp)
+        assert rc == hr.ERR_INVALID and a["status"] == hr.ERR_INVALID
+
+
+# ---- the product's tables vs the oracle's (two independent builds of the same published formulas) --
+
+def _tables_exe():
+    exe = "/tmp/hr_tables_dump"
+    src = os.path.join(ROOT, "tests", "tables_dump.cpp")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", src, os.path.join(ROOT, "headroom_amd", "csrc", "hr_tables.cpp"),
+                           "-o", exe])
+    return exe
+
+
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_product_tables_match_oracle(oracle, fs):
+    out = subprocess.check_output([_tables_exe(), str(fs)]).decode().split()
+    vals = list(map(float, out))
+    k = oracle.kcoef(fs)
+    mine = vals[:7]
+    ref = [k["pre_b"][0], k["pre_b"][1], k["pre_b"][2], k["pre_a"][1], k["pre_a"][2], k["rlb_a"][1], k["rlb_a"][2]]
+    assert mine == ref  # bit-identical: same formulas, same libm
+    P, step = int(vals[7]), int(vals[8])
+    oP, ostep, otaps = oracle.swr_bank(fs)
+    assert (P, step) == (oP, ostep)
+    taps = np.array(vals[10:10 + (P + 1) * 32]).reshape(P + 1, 32)
+    assert np.array_equal(taps, otaps)
+    assert vals[9] < 1e-25  # |M^3|: the carry series is converged after three hops
+
+
+def test_cpu_carry_algebra(oracle):
+    """The zero-state + carry-correction algebra of k_hop_zero_state / k_hop_combine, on the host."""
+    exe = "/tmp/hr_carry_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", "-c",
+                           os.path.join(ROOT, "tests", "cpu_carry_check.cpp"), "-o", "/tmp/hr_cc_a.o"])
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-c", os.path.join(ROOT, "headroom_amd", "csrc", "hr_tables.cpp"),
+                           "-o", "/tmp/hr_cc_b.o"])
+    subprocess.check_call(["g++", "/tmp/hr_cc_a.o", "/tmp/hr_cc_b.o", oracle.LIB_PATH, "-o", exe, "-lm",
+                           "-Wl,-rpath," + os.path.dirname(oracle.LIB_PATH)])
+    for args in (("48000", "2", "1", "0"), ("44100", "2", "2", "1"), ("96000", "1", "3", "2")):
+        subprocess.check_call([exe, *args], stdout=subprocess.DEVNULL)

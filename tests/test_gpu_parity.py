@@ -1,0 +1,277 @@
+"""GPU parity tests: the HIP path, called through the C ABI, against the CPU oracle on the same inputs.
+
+Bars (BASELINE.json north_star): block energies within 1e-6 relative of the f64 CPU reference (asserted
+here at 1e-9), integrated loudness within 0.01 LU (asserted at 1e-6 LU), true peak within 0.05 dB
+(asserted bit-identical: the GPU evaluates the candidates of the maximum in the oracle's own f64 FMA
+order).  "Parity unpinned" with respect to FFmpeg itself: see oracle/hr_oracle.h.
+"""
+import math
+
+import numpy as np
+import pytest
+
+import headroom_amd as hr
+import signals
+
+pytestmark = pytest.mark.gpu
+
+GATES = {"ebur128": 0, "exact": 1, "loudnorm": 2}
+TPS = {"swr192k": 0, "bs1770": 1, "sample": 2}
+
+
+@pytest.fixture(scope="module")
+def meters():
+    cache = {}
+
+    def get(gate="ebur128", tp="swr192k", engine=0):
+        key = (gate, tp, engine)
+        if key not in cache:
+            cache[key] = hr.Meter(device=0, gate_mode=GATES[gate], tp_mode=TPS[tp], engine=engine)
+        return cache[key]
+
+    yield get
+    for m in cache.values():
+        m.close()
+
+
+def check_against_oracle(oracle, m, pcm, fs, gate="ebur128", tp="swr192k", **kw):
+    ref = oracle.measure(pcm, fs, gate_mode=GATES[gate], tp_mode=TPS[tp], **kw)
+    got = m.analyze(pcm, fs, **kw)
+    assert got["status"] == 0
+    assert got["n_blocks"] == ref["n_blocks"]
+    assert got["n_gated"] == ref["n_gated"]
+    if math.isfinite(ref["integrated_lufs"]):
+        assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6, (got, ref)
+        assert abs(got["rel_threshold_lufs"] - ref["rel_threshold_lufs"]) < 1e-6, (got, ref)
+    else:
+        assert got["integrated_lufs"] == ref["integrated_lufs"]
+    assert got["peak_per_ch"] == ref["peak_per_ch"], (got, ref)  # bit-identical f64
+    assert got["true_peak_dbtp"] == ref["true_peak_dbtp"]
+    return got, ref
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_block_energies_match_oracle(oracle, meters, fs, engine):
+    pcm = signals.seeded_noise(100 + fs, fs * 5 + 1234, 2, -18.0)
+    pcm[: fs] *= 0.01
+    m = meters(engine=engine)
+    H, P = m.block_energies(hr.TrackSpec(pcm, fs))
+    Href = oracle.hop_sums(pcm, fs)
+    Pref = oracle.block_powers(Href, fs)
+    assert H.shape == Href.shape and P.shape == Pref.shape
+    assert np.max(np.abs(H / Href - 1)) < 1e-9
+    assert np.max(np.abs(P / Pref - 1)) < 1e-9
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("gate", ["ebur128", "exact", "loudnorm"])
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_measure_noise(oracle, meters, fs, gate, engine):
+    pcm = signals.seeded_noise(7 + fs, fs * 6 + 77, 2, -16.0)
+    pcm[: 2 * fs] *= 0.004
+    check_against_oracle(oracle, meters(gate, "swr192k", engine), pcm, fs, gate, "swr192k")
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("tp", ["bs1770", "sample"])
+@pytest.mark.parametrize("fs", [44100, 48000, 96000, 192000])
+def test_other_true_peak_modes(oracle, meters, fs, tp, engine):
+    pcm = signals.seeded_noise(9 + fs, fs * 2 + 5, 2, -10.0)
+    check_against_oracle(oracle, meters("ebur128", tp, engine), pcm, fs, "ebur128", tp)
+
+
+def test_192k_input_true_peak_is_sample_peak(oracle, meters):
+    pcm = signals.seeded_noise(5, 192000 * 1, 2, -10.0)
+    got, ref = check_against_oracle(oracle, meters(), pcm, 192000)
+    assert got["peak_per_ch"][0] == float(np.max(np.abs(pcm[:, 0])))
+
+
+@pytest.mark.parametrize("case", [1, 3, 4, 5, 6, 16, 19])
+def test_ebu3341_cases_on_gpu(oracle, meters, case):
+    pcm, exp_i, exp_tp = signals.ebu3341_case(case)
+    got, ref = check_against_oracle(oracle, meters(), pcm, 48000)
+    if exp_i is not None:
+        assert abs(got["integrated_lufs"] - exp_i) <= 0.1
+    if exp_tp is not None:
+        assert exp_tp - 0.4 <= got["true_peak_dbtp"] <= exp_tp + 0.2
+
+
+def test_sweep_square_dc(oracle, meters):
+    fs = 48000
+    n = np.arange(fs * 3)
+    sweep = 0.5 * np.sin(2 * np.pi * (20.0 + 3000.0 * n / fs) * n / fs)
+    square = 0.999 * np.sign(np.sin(2 * np.pi * 441.0 * n / fs))
+    dc = np.full(n.shape, 0.25)
+    for x in (sweep, square, dc):
+        pcm = signals.stereo(x)
+        m = meters()
+        H, P = m.block_energies(hr.TrackSpec(pcm, fs))
+        Href = oracle.hop_sums(pcm, fs)
+        # relative to the loudest hop: a pure DC input decays to ~1e-30 after the high-pass
+        assert np.max(np.abs(H - Href)) <= 1e-9 * np.max(Href)
+        check_against_oracle(oracle, m, pcm, fs)
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+def test_config4_96k_s24_5_1(oracle, meters, engine):
+    """BASELINE config 4: 96 kHz, 24-bit packed, 5.1 (LFE excluded from loudness, true peak on all six)."""
+    fs, secs = 96000, 2
+    x = signals.seeded_noise(44, fs * secs, 6, -14.0).astype(np.float64)
+    x[:, 3] = signals.sine(fs, 50.0, -4.0, secs)  # loud LFE
+    raw = signals.to_s24_bytes(x)
+    m = meters(engine=engine)
+    got, ref = check_against_oracle(oracle, m, raw, fs, channels=6, fmt=hr.FMT_S24)
+    assert got["peak_per_ch"][3] == max(got["peak_per_ch"])
+    x2 = x.copy()
+    x2[:, 3] = 0
+    got2 = m.analyze(signals.to_s24_bytes(x2), fs, channels=6, fmt=hr.FMT_S24)
+    assert got2["integrated_lufs"] == got["integrated_lufs"]  # LFE does not touch loudness
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+def test_formats_and_channel_counts(oracle, meters, engine):
+    fs = 44100
+    x = signals.seeded_noise(21, fs * 2 + 11, 2, -9.0)
+    m = meters(engine=engine)
+    check_against_oracle(oracle, m, signals.to_s16(x), fs)
+    check_against_oracle(oracle, m, (x.astype(np.float64) * 2147483648.0).astype(np.int32), fs)
+    check_against_oracle(oracle, m, x.astype(np.float64), fs)
+    check_against_oracle(oracle, m, x[:, :1].copy(), fs)  # mono
+    x8 = signals.seeded_noise(22, fs * 1 + 3, 8, -9.0)
+    check_against_oracle(oracle, m, x8, fs)
+    w = np.array([1.0, 0.5], dtype=np.float32)
+    check_against_oracle(oracle, m, x, fs, weights=w)
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+def test_edge_cases(oracle, meters, engine):
+    m = meters(engine=engine)
+    fs = 48000
+    r = m.analyze(np.zeros((fs * 2, 2), dtype=np.float32), fs)
+    assert r["integrated_lufs"] == -math.inf and r["true_peak_dbtp"] == -math.inf and r["n_gated"] == 0
+    assert r["n_blocks"] == 17 and r["status"] == 0
+    rc, a = hr.gain_decision(r["integrated_lufs"], r["true_peak_dbtp"])
+    assert rc == hr.ERR_INVALID  # the caller's non-finite rule (src/analyzer.rs:284) still fires
+    short = signals.stereo(signals.sine(fs, 1000.0, -20.0, 0.39))
+    got, ref = check_against_oracle(oracle, m, short, fs)
+    assert got["n_blocks"] == 0 and got["integrated_lufs"] == -math.inf
+    tiny = np.ones((20, 2), dtype=np.float32)
+    check_against_oracle(oracle, m, tiny, fs)
+    exactly = signals.seeded_noise(1, 4800 * 4, 2, -20.0)  # exactly one block
+    got, ref = check_against_oracle(oracle, m, exactly, fs)
+    assert got["n_blocks"] == 1
+    r = m.analyze(np.zeros((0, 2), dtype=np.float32), fs)
+    assert r["status"] == 0 and r["n_blocks"] == 0 and r["integrated_lufs"] == -math.inf
+    ragged = signals.seeded_noise(2, 4800 * 7 + 4799, 2, -20.0)  # trailing partial hop is discarded
+    got, ref = check_against_oracle(oracle, m, ragged, fs)
+    assert got["n_blocks"] == 4
+
+
+def test_batch_order_errors_and_device_pcm(oracle, meters):
+    import torch
+    m = meters()
+    fs = 44100
+    a = signals.seeded_noise(31, fs * 3, 2, -12.0)
+    b = signals.seeded_noise(32, fs * 2 + 9, 2, -25.0)
+    c = signals.seeded_noise(33, 48000 * 2, 1, -6.0)
+    td = torch.from_numpy(b).cuda()
+    specs = [hr.TrackSpec(a, fs), hr.TrackSpec(a, 22050),  # 22.05 kHz would need swr's phase interpolation
+             hr.TrackSpec(td, fs), hr.TrackSpec(c, 48000), hr.TrackSpec(a, fs)]
+    bad = hr.TrackSpec(a, fs)
+    bad.c.channels = 9
+    specs.append(bad)
+    res = m.analyze_batch(specs)
+    assert [r["status"] for r in res] == [0, hr.ERR_RATE, 0, 0, 0, hr.ERR_FORMAT]
+    ra, rb, rc_ = (oracle.measure(x, f) for x, f in ((a, fs), (b, fs), (c, 48000)))
+    for got, ref in ((res[0], ra), (res[2], rb), (res[3], rc_), (res[4], ra)):
+        assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+        assert got["peak_per_ch"] == ref["peak_per_ch"]
+    assert m.analyze_batch([]) == []
+
+
+def test_small_staging_splits_batch(oracle):
+    fs = 48000
+    tracks = [signals.seeded_noise(50 + i, fs * 2, 2, -15.0 - i) for i in range(5)]
+    with hr.Meter(stage_bytes=1 << 20) as m:  # 1 MiB: every track is its own group
+        res = m.analyze_batch([hr.TrackSpec(t, fs) for t in tracks])
+    for t, r in zip(tracks, res):
+        ref = oracle.measure(t, fs)
+        assert abs(r["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6 and r["peak_per_ch"] == ref["peak_per_ch"]
+
+
+def test_synth_fill_matches_oracle_generator(oracle, meters):
+    import torch
+    m = meters()
+    for fs, ch, frames in ((44100, 2, 44100 * 25), (48000, 1, 48000 * 3), (96000, 6, 9600 * 7)):
+        buf = torch.empty((frames, ch), dtype=torch.float32, device="cuda")
+        m.synth_fill(buf.data_ptr(), 987654321 + fs, fs, ch, frames)
+        torch.cuda.synchronize()
+        ref = oracle.synth_track(987654321 + fs, fs, ch, frames)
+        assert np.array_equal(buf.cpu().numpy(), ref)
+
+
+def test_time_shards_equal_whole_stream(oracle, meters):
+    """BASELINE config 5 on one device: 3 shards with IIR carry hand-off, boundary blocks, FIR halos."""
+    fs = 48000
+    pcm = signals.seeded_noise(77, 4800 * 61 + 1000, 2, -17.0)
+    pcm[: fs * 2] *= 0.002
+    for gate in ("ebur128", "loudnorm"):
+        m = meters(gate)
+        whole = m.analyze(pcm, fs)
+        ref = oracle.measure(pcm, fs, gate_mode=GATES[gate])
+        cuts = [0, 4800 * 20, 4800 * 27, pcm.shape[0]]
+        shards = [hr.TrackSpec(pcm[cuts[i]:cuts[i + 1]].copy(), fs) for i in range(3)]
+        heads = [m.shard_head(s) for s in shards]
+        edges, partials = [], []
+        # pass 1 on every shard (on a node: one per rank), edges travel to the right neighbour
+        m2 = [hr.Meter(gate_mode=GATES[gate]) for _ in range(3)]
+        for i, s in enumerate(shards):
+            left_tail = np.ascontiguousarray(np.ctypeslib.as_array(edges[i - 1].tail)) if i else None
+            right_head = heads[i + 1] if i < 2 else None
+            edges.append(m2[i].shard_pass1(s, left_tail, right_head))
+        for i in range(3):
+            partials.append(m2[i].shard_pass2(edges[i - 1] if i else None))
+        red = hr.HrShardPartial()
+        for p in partials:  # the all-reduce
+            for b in range(8001):
+                red.hist[b] += p.hist[b]
+            red.sum_kept += p.sum_kept
+            red.n_kept += p.n_kept
+            red.n_blocks += p.n_blocks
+            for c in range(2):
+                red.peak_per_ch[c] = max(red.peak_per_ch[c], p.peak_per_ch[c])
+        got = m2[0].shard_finish(red, 2)
+        for mm in m2:
+            mm.close()
+        assert got["n_blocks"] == whole["n_blocks"] == ref["n_blocks"]
+        assert got["n_gated"] == whole["n_gated"]
+        assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
+        assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+        assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+
+
+def test_full_size_track_properties(oracle, meters):
+    """A full 3-minute 44.1 kHz track (BASELINE config 1/2 shape), generated in HBM: oracle parity on the
+    whole track, plus size-independent properties: gain linearity (+6.0206 dB exactly doubles) and
+    invariance under channel swap."""
+    import torch
+    m = meters()
+    fs, frames = 44100, 44100 * 180
+    buf = torch.empty((frames, 2), dtype=torch.float32, device="cuda")
+    m.synth_fill(buf.data_ptr(), 4242, fs, 2, frames)
+    torch.cuda.synchronize()
+    got = m.analyze(buf, fs)
+    assert got["n_blocks"] == 1797
+    ref = oracle.measure(buf.cpu().numpy(), fs)
+    assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+    assert got["peak_per_ch"] == ref["peak_per_ch"]
+    assert got["n_gated"] == ref["n_gated"]
+    half = (buf * 0.5).contiguous()
+    g2 = m.analyze(half, fs)
+    assert g2["peak_per_ch"] == [p * 0.5 for p in got["peak_per_ch"]]
+    assert abs((got["integrated_lufs"] - g2["integrated_lufs"]) - 20 * math.log10(2)) < 0.011  # 0.01 LU bins
+    swapped = buf.flip(1).contiguous()
+    g3 = m.analyze(swapped, fs)
+    assert g3["peak_per_ch"] == got["peak_per_ch"][::-1]
+    assert abs(g3["integrated_lufs"] - got["integrated_lufs"]) < 1e-9
