@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the loudness + true-peak hot path on synthetic PCM resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on): a 1,000-track batch of
+3-minute 44.1 kHz stereo f32 PCM per GPU (63.5 GB, generated in HBM by hr_synth_fill).  One step = one
+hr_analyze_batch over the whole batch: integrated LUFS (ebur128 gating) + dBTP (192 kHz interpolation)
+for every track.  Tracks are independent, so with N GPUs every rank analyses its own 1,000 tracks and no
+data-path collective exists ("scaling": "weak").  Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+FS = 44100
+CH = 2
+SECONDS = 180
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def cpu_baseline(n_tracks, threads):
+    """The oracle (a scalar f64 restatement of FFmpeg's algorithm: "port") timed on the host cores on a
+    bounded sample of the same workload: n_tracks full 3-minute tracks, one thread per track (mirrors one
+    ffmpeg process per rayon worker, src/cli.rs:407)."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    import oracle_lib
+    oracle_lib.build()
+    frames = FS * SECONDS
+    tracks = [oracle_lib.synth_track(1000 + i, FS, CH, frames) for i in range(n_tracks)]
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        res = list(ex.map(lambda t: oracle_lib.measure(t, FS), tracks))
+    dt = time.perf_counter() - t0
+    hours = n_tracks * SECONDS / 3600.0
+    return {"value": hours / dt, "unit": "audio-hours/s", "cores": threads, "kind": "port",
+            "sample": f"{n_tracks} x {SECONDS} s 44.1 kHz stereo f32 tracks of the same synthetic generator, "
+                      f"one thread per track, oracle mode ebur128 gating + 192 kHz interpolation, {dt:.2f} s wall"}, res, tracks
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--tracks", type=int, default=1000, help="tracks per GPU (default: BASELINE config 2)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+
+    import headroom_amd as hr
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    frames = FS * SECONDS
+    n_tracks = args.tracks
+    meter = hr.Meter(device=local, engine=args.engine)
+    pcm = torch.empty((n_tracks, frames, CH), dtype=torch.float32, device=dev)
+    for i in range(n_tracks):
+        meter.synth_fill(pcm[i].data_ptr(), 1000 + rank * n_tracks + i, FS, CH, frames)
+    torch.cuda.synchronize()
+    specs = [hr.TrackSpec(pcm[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_F32, frames=frames) for i in range(n_tracks)]
+    bytes_per_step = n_tracks * frames * CH * 4
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    res = None
+    for _ in range(args.warmup):
+        res = meter.analyze_batch(specs)
+    main_ms = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = meter.analyze_batch(specs)
+        main_ms.append(meter.last_timing()[1])
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert all(r["status"] == 0 for r in res)
+
+    if rank == 0:
+        hours_per_step = world * n_tracks * SECONDS / 3600.0
+        value = hours_per_step * args.steps / elapsed
+        kernel_ms = sum(main_ms) / max(len(main_ms), 1)
+        achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        line = {
+            "metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": value, "unit": "audio-hours/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s 44.1 kHz stereo f32 PCM resident in HBM "
+                                   "(BASELINE configs[1]); per-track integrated LUFS (ebur128 gating) + dBTP (192 kHz)",
+                       "tracks_per_gpu": n_tracks, "bytes_per_gpu": bytes_per_step, "parallelism": f"track-sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "K-weight + true-peak pass (HIP events on the library stream, mean over timed steps)",
+                         "kernel_ms": kernel_ms},
+            "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = min(16, os.cpu_count() or 1)
+            base, ref, cpu_tracks = cpu_baseline(threads, threads)
+            line["cpu_baseline"] = base
+            # the same tracks (seeds 1000..) are the first tracks of rank 0's batch: parity spot check
+            worst_i = max(abs(res[i]["integrated_lufs"] - ref[i]["integrated_lufs"]) for i in range(len(ref)))
+            same_tp = all(res[i]["peak_per_ch"] == ref[i]["peak_per_ch"] for i in range(len(ref)))
+            line["parity_check"] = {"tracks": len(ref), "max_abs_lufs_diff": worst_i, "true_peak_bit_identical": same_tp}
+        print(json.dumps(line), flush=True)
+    meter.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

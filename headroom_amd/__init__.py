@@ -76,6 +76,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(make -C headroom_amd/csrc). The meter has no CPU fallback.")
+    # PyTorch's ROCm wheel bundles its own HIP runtime.  One process must use one runtime, and torch
+    # cannot start on a runtime somebody else loaded first ("No HIP GPUs are available"), so when torch
+    # is installed let it load its runtime before this library binds to libamdhip64 by SONAME.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     L.hr_device_count.restype = C.c_int
     L.hr_init.argtypes = [C.POINTER(HrConfig), C.POINTER(C.c_void_p)]

@@ -43,6 +43,8 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+constexpr uint32_t kPeakSpan = 8192;  // positions per workgroup of the generic true-peak kernels
+
 size_t fmt_bytes(int fmt)
 {
     switch (fmt) {
@@ -231,17 +233,18 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         for (uint64_t p = 0; p < pairs; p += 256) items.push_back({static_cast<uint32_t>(i), 0, p});
     }
     comb_span.n = items.size() - comb_span.off;
-    // kind 0 = the configured interpolator, kind 1 = sample peak (192 kHz input under HR_TP_SWR192K:
-    // libswresample does not resample, f_ebur128's "true peak" is then the sample peak)
+    // kind 0 = the configured interpolator, kind 1 = sample peak (192 kHz input: libswresample does not
+    // resample, so f_ebur128's "true peak" is the sample peak; BS.1770 asks for no oversampling there)
     for (int f = 0; f < 5; f++)
         for (int kind = 0; kind < 2; kind++) {
             pk_span[f][kind].off = items.size();
             if (do_peaks)
                 for (size_t i = 0; i < nt; i++) {
                     if (g.fmts[i] != f) continue;
-                    const bool plain = ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0;
+                    const bool plain = (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0) ||
+                                       (ctx->cfg.tp_mode == HR_TP_BS1770 && g.descs[i].fs >= 192000);
                     if (plain != (kind == 1)) continue;
-                    for (uint64_t n = 0; n < g.descs[i].frames; n += 256) items.push_back({static_cast<uint32_t>(i), 0, n});
+                    for (uint64_t n = 0; n < g.descs[i].frames; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
                 }
             pk_span[f][kind].n = items.size() - pk_span[f][kind].off;
         }
@@ -261,7 +264,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             for (int kind = 0; kind < 2; kind++) {
                 if (!pk_span[f][kind].n) continue;
                 launch_true_peak_generic(f, kind == 1 ? HR_TP_SAMPLE : ctx->cfg.tp_mode, dt, dr, ctx->bs_taps.as<double>(),
-                                         di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n),
+                                         di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n), kPeakSpan,
                                          ctx->peaks.as<unsigned long long>(), st);
             }
     }

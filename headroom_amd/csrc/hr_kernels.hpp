@@ -17,9 +17,9 @@ void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
                        const double *ln_bounds, TrackOut *outs, hipStream_t st);
-// tp_kind: 0 swr192k, 1 bs1770, 2 sample peak
+// tp_kind: 0 swr192k, 1 bs1770, 2 sample peak; every item covers `span` (multiple of 256) positions
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
-                              const double *bs_taps, const WorkItem *items, uint32_t n_items,
+                              const double *bs_taps, const WorkItem *items, uint32_t n_items, uint32_t span,
                               unsigned long long *peaks, hipStream_t st);
 
 // hr_synth.hip

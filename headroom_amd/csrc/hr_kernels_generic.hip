@@ -371,25 +371,27 @@ __device__ __forceinline__ void peak_commit(double m, unsigned long long *slot)
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(slot, static_cast<unsigned long long>(__double_as_longlong(m)));
 }
 
+// Each workgroup covers `span` consecutive positions starting at item.first (positions past the valid
+// range are skipped), 256 at a time.
 template <int FMT>
 __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restrict__ tracks,
                                                        const RateDev *__restrict__ rates,
-                                                       const WorkItem *__restrict__ items,
+                                                       const WorkItem *__restrict__ items, uint32_t span,
                                                        unsigned long long *__restrict__ peaks)
 {
     const WorkItem it = items[blockIdx.x];
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
     const int64_t N = static_cast<int64_t>(t.frames);
-    const int64_t pos = static_cast<int64_t>(it.first) + threadIdx.x;
     const int P = r.swr_phases, step = r.swr_step;
     // an output at position pos needs frames pos-15 .. pos+16
     const int64_t last_pos = t.stream_end ? N - 17 : N - 1;
-    const bool active = t.tp_enabled && pos <= last_pos && pos < N;
     const int C = t.ch;
     for (int c = 0; c < C; c++) {
         double m = 0.0;
-        if (active) {
+        for (uint32_t off = 0; off < span; off += 256) {
+            const int64_t pos = static_cast<int64_t>(it.first) + off + threadIdx.x;
+            if (!(t.tp_enabled && pos <= last_pos && pos < N)) continue;
             double x[kSwrTaps];
 #pragma unroll
             for (int i = 0; i < kSwrTaps; i++) x[i] = fetch<FMT>(t, c, pos - 15 + i, true);
@@ -413,18 +415,19 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
 template <int FMT>
 __global__ void __launch_bounds__(256) k_true_peak_bs1770(const TrackDesc *__restrict__ tracks,
                                                           const double *__restrict__ taps /*[4][12]*/,
-                                                          const WorkItem *__restrict__ items,
+                                                          const WorkItem *__restrict__ items, uint32_t span,
                                                           unsigned long long *__restrict__ peaks)
 {
     const WorkItem it = items[blockIdx.x];
     const TrackDesc &t = tracks[it.track];
     const int64_t N = static_cast<int64_t>(t.frames);
-    const int64_t n = static_cast<int64_t>(it.first) + threadIdx.x;
     const int stride = t.fs < 96000 ? 1 : 2;  // x4 below 96 kHz, x2 below 192 kHz
     const int C = t.ch;
     for (int c = 0; c < C; c++) {
         double m = 0.0;
-        if (n < N) {
+        for (uint32_t off = 0; off < span; off += 256) {
+            const int64_t n = static_cast<int64_t>(it.first) + off + threadIdx.x;
+            if (n >= N) continue;
             double x[12];
 #pragma unroll
             for (int k = 0; k < 12; k++) x[k] = fetch<FMT>(t, c, n - k, false);
@@ -442,17 +445,21 @@ __global__ void __launch_bounds__(256) k_true_peak_bs1770(const TrackDesc *__res
 
 template <int FMT>
 __global__ void __launch_bounds__(256) k_sample_peak(const TrackDesc *__restrict__ tracks,
-                                                     const WorkItem *__restrict__ items,
+                                                     const WorkItem *__restrict__ items, uint32_t span,
                                                      unsigned long long *__restrict__ peaks)
 {
     const WorkItem it = items[blockIdx.x];
     const TrackDesc &t = tracks[it.track];
     const int64_t N = static_cast<int64_t>(t.frames);
-    const int64_t n = static_cast<int64_t>(it.first) + threadIdx.x;
     const int C = t.ch;
     for (int c = 0; c < C; c++) {
         double m = 0.0;
-        if (n < N) m = fabs(ld_sample<FMT>(t.pcm, static_cast<uint64_t>(n) * C + c));
+        for (uint32_t off = 0; off < span; off += 256) {
+            const int64_t n = static_cast<int64_t>(it.first) + off + threadIdx.x;
+            if (n >= N) continue;
+            const double a = fabs(ld_sample<FMT>(t.pcm, static_cast<uint64_t>(n) * C + c));
+            m = a > m ? a : m;
+        }
         peak_commit(m, &peaks[static_cast<size_t>(it.track) * kMaxCh + c]);
     }
 }
@@ -501,16 +508,16 @@ void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode
 }
 
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
-                              const double *bs_taps, const WorkItem *items, uint32_t n_items,
+                              const double *bs_taps, const WorkItem *items, uint32_t n_items, uint32_t span,
                               unsigned long long *peaks, hipStream_t st)
 {
     if (!n_items) return;
     if (tp_kind == 0) {
-        HR_FMT_DISPATCH(fmt, (k_true_peak_swr<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, rates, items, peaks)));
+        HR_FMT_DISPATCH(fmt, (k_true_peak_swr<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, rates, items, span, peaks)));
     } else if (tp_kind == 1) {
-        HR_FMT_DISPATCH(fmt, (k_true_peak_bs1770<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, bs_taps, items, peaks)));
+        HR_FMT_DISPATCH(fmt, (k_true_peak_bs1770<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, bs_taps, items, span, peaks)));
     } else {
-        HR_FMT_DISPATCH(fmt, (k_sample_peak<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, items, peaks)));
+        HR_FMT_DISPATCH(fmt, (k_sample_peak<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, items, span, peaks)));
     }
 }
 
