@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <mutex>
@@ -74,10 +75,12 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
 
     // workspace (grow-only)
-    DevBuf tracks_d, items_d, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf tracks_d, items_d, fitems_d, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
+    std::vector<FusedItem> h_fitems;
+    int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     float last_total_ms = 0, last_main_ms = 0;
@@ -134,12 +137,17 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
         HIPCHK(hipMalloc(&tp, rt->swr_taps.size() * sizeof(double)));
         ctx->rate_allocs.push_back(tp);
         HIPCHK(hipMemcpy(tp, rt->swr_taps.data(), rt->swr_taps.size() * sizeof(double), hipMemcpyHostToDevice));
-        std::vector<float> t32(rt->swr_taps.begin(), rt->swr_taps.end());
-        HIPCHK(hipMalloc(&tp32, t32.size() * sizeof(float)));
-        ctx->rate_allocs.push_back(tp32);
-        HIPCHK(hipMemcpy(tp32, t32.data(), t32.size() * sizeof(float), hipMemcpyHostToDevice));
         rd.swr_taps = static_cast<const double *>(tp);
-        rd.swr_taps32 = static_cast<const float *>(tp32);
+        (void)tp32;
+        if (!rt->tp_atab.empty()) {
+            void *at = nullptr;
+            HIPCHK(hipMalloc(&at, rt->tp_atab.size() * sizeof(uint16_t)));
+            ctx->rate_allocs.push_back(at);
+            HIPCHK(hipMemcpy(at, rt->tp_atab.data(), rt->tp_atab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            rd.tp_atab = at;
+            rd.tp_np = rt->tp_np;
+            rd.tp_mt = rt->tp_mt;
+        }
     }
     ctx->rate_fs.push_back(fs);
     ctx->rates_h.push_back(rd);
@@ -213,7 +221,35 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
     const RateDev *dr = ctx->rates_d.as<RateDev>();
 
-    // work items: [fmt] hop items, combine items, [fmt][kind] peak items -- one upload
+    // Which tracks take the fused kernel (hr_kernels_fused.hip)?  Stereo f32, 16-byte aligned, at least two
+    // hops; its true-peak half additionally needs HR_TP_SWR192K and the rate's f16 tile table.  The fused
+    // kernel covers hops 0 .. n_hops-2; the last hop and the ragged tail stay on the generic kernels.
+    std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0);
+    for (size_t i = 0; i < nt; i++) {
+        const TrackDesc &d = g.descs[i];
+        const bool ok = ctx->cfg.engine != 1 && d.fmt == HR_FMT_F32 && d.ch == 2 && d.n_hops >= 2 && d.hop >= 64 &&
+                        (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
+        fkw[i] = ok;
+        ftp[i] = ok && do_peaks && ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[d.rate_idx].tp_atab != nullptr;
+    }
+    std::vector<FusedItem> &fitems = ctx->h_fitems;
+    fitems.clear();
+    size_t fused_split = 0;  // [0, split): K-weight + true peak, [split, end): K-weight only
+    for (int pass = 0; pass < 2; pass++) {
+        for (size_t i = 0; i < nt; i++) {
+            if (!fkw[i] || (ftp[i] != 0) != (pass == 0)) continue;
+            const uint64_t interior = g.descs[i].n_hops - 1;
+            for (uint64_t h = 0; h < interior; h += 64)
+                fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
+        }
+        if (pass == 0) fused_split = fitems.size();
+    }
+    if (!fitems.empty()) {
+        rc = upload(ctx->fitems_d, fitems.data(), fitems.size() * sizeof(FusedItem), st);
+        if (rc) return rc;
+    }
+
+    // work items of the generic kernels: [fmt] hop items, combine items, [fmt][kind] peak items -- one upload
     std::vector<WorkItem> &items = ctx->h_items;
     items.clear();
     struct Span { size_t off, n; };
@@ -222,7 +258,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         hop_span[f].off = items.size();
         for (size_t i = 0; i < nt; i++) {
             if (g.fmts[i] != f) continue;
-            for (uint64_t h = 0; h < g.descs[i].n_hops; h += 256) items.push_back({static_cast<uint32_t>(i), 0, h});
+            for (uint64_t h = fkw[i] ? g.descs[i].n_hops - 1 : 0; h < g.descs[i].n_hops; h += 256)
+                items.push_back({static_cast<uint32_t>(i), 0, h});
         }
         hop_span[f].n = items.size() - hop_span[f].off;
     }
@@ -244,7 +281,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     const bool plain = (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0) ||
                                        (ctx->cfg.tp_mode == HR_TP_BS1770 && g.descs[i].fs >= 192000);
                     if (plain != (kind == 1)) continue;
-                    for (uint64_t n = 0; n < g.descs[i].frames; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
+                    const uint64_t n0 = ftp[i] ? (g.descs[i].n_hops - 1) * g.descs[i].hop : 0;
+                    for (uint64_t n = n0; n < g.descs[i].frames; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
                 }
             pk_span[f][kind].n = items.size() - pk_span[f][kind].off;
         }
@@ -255,11 +293,21 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     const WorkItem *di = ctx->items_d.as<WorkItem>();
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
+    if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
+    {
+        const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
+        // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
+        const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
+        launch_fused_f32s_dbg(dt, dr, fi, static_cast<uint32_t>(fused_split), ctx->recs.as<HopRec>(),
+                              ctx->peaks.as<unsigned long long>(), v0, dbg, st);
+        launch_fused_f32s_dbg(dt, dr, fi + fused_split, static_cast<uint32_t>(fitems.size() - fused_split),
+                              ctx->recs.as<HopRec>(), ctx->peaks.as<unsigned long long>(), v0 == 3 ? 3 : 1, dbg, st);
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
     for (int f = 0; f < 5; f++)
         launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), st);
     if (do_peaks) {
-        HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
         for (int f = 0; f < 5; f++)
             for (int kind = 0; kind < 2; kind++) {
                 if (!pk_span[f][kind].n) continue;
@@ -268,7 +316,6 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                                          ctx->peaks.as<unsigned long long>(), st);
             }
     }
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
     ctx->comb_off = comb_span.off;
     ctx->comb_n = comb_span.n;
     if (do_combine)
@@ -395,6 +442,7 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     hr_ctx *ctx = new hr_ctx();
     ctx->cfg = c;
     if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
+    if (const char *ab = std::getenv("HR_ABLATE")) ctx->ablate = std::atoi(ab);
     if (c.stream) ctx->stream = static_cast<hipStream_t>(c.stream);
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HR_ERR_HIP; }
@@ -418,7 +466,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
-                      &ctx->items_d, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->items_d, &ctx->fitems_d, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);

@@ -20,7 +20,8 @@ struct RateDev {
     double M1[16], M2[16];
     const double *g;         // [hop][4]
     const double *swr_taps;  // [(phases+1)][32] f64
-    const float *swr_taps32; // same, f32 (screen kernels)
+    const void *tp_atab;     // f16 A fragments of the MFMA screen, [tp_np][tp_mt][3][64][8 halfs]; nullptr: no fused path
+    int32_t tp_np, tp_mt;
     uint32_t hop;
     int32_t swr_phases, swr_step;
     double swr_l1;
@@ -59,6 +60,13 @@ struct WorkItem {
     uint32_t track;
     uint32_t pad;
     uint64_t first;  // first hop (K-weight kernels) or first frame (true-peak kernels)
+};
+
+// one wave's share of the fused kernel: up to 64 consecutive interior hops of one track
+struct FusedItem {
+    uint32_t track;
+    uint32_t n_rows;
+    uint64_t first_hop;
 };
 
 struct TrackOut {  // what the finalize kernel hands to the host

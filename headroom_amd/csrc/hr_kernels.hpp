@@ -22,6 +22,14 @@ void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, con
                               const double *bs_taps, const WorkItem *items, uint32_t n_items, uint32_t span,
                               unsigned long long *peaks, hipStream_t st);
 
+// hr_kernels_fused.hip: stereo f32, swr true peak.  variant 0 = full; 1 = K-weight only, 2 = true peak only,
+// 3 = data movement only (ablation builds for the roofline analysis)
+void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
+                       HopRec *recs, unsigned long long *peaks, int variant, hipStream_t st);
+
+void launch_fused_f32s_dbg(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
+                           HopRec *recs, unsigned long long *peaks, int variant, int dbg, hipStream_t st);
+
 // hr_synth.hip
 struct SynthPar {
     float a_noise, a_sine, burst;

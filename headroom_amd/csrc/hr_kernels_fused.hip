@@ -1,0 +1,472 @@
+// hr_kernels_fused.hip -- the hot kernel: K-weighting + hop energies + true peak in ONE read of the PCM.
+// Stereo f32 interleaved input, libswresample-style true peak (HR_TP_SWR192K).
+//
+// Decomposition.  A wave owns 64 consecutive interior hops (100 ms each) of one track, one hop ("row") per
+// lane; the 64 rows advance in lock step, 16 frames (one 128-byte piece per row) per step.
+//   * HBM -> LDS: eight global_load_lds_dwordx4 per step move the 64 pieces (8 KiB) with every 128-byte
+//     piece read by 8 adjacent lanes (full cache lines), no VGPR staging.  The LDS image is lane-linear, so
+//     the bank swizzle is applied on the SOURCE chunk index (chunk ^ ((row>>1)&7)) and undone by the reader:
+//     each lane then reads its own row with eight conflict-free ds_read_b128.
+//   * K1/K2a (VALU, f64): every hop is filtered from ZERO state (input history taken from the data), and
+//     records energy e0, four correction dot products q and its end state; k_hop_combine later applies the
+//     exact carry-in state (H = e0 + 2 s.q + s'Gs).  Same operations in the same order as
+//     k_hop_zero_state, so the records are bit-identical to the generic kernel's.
+//   * K3 (MFMA, f16 screen + exact f64 refinement): the 16 positions of a tile and their 4.35 (44.1 kHz) or
+//     4 (48 kHz) interpolated outputs each are a [<=96 outputs] x [48-frame window] coefficient tile times a
+//     [48] x [64 rows] signal matrix: v_mfma_f32_32x32x16_f16 with the rows as the N dimension.  The B
+//     fragments come straight from the lane's own registers (v_cvt_pkrtz + v_permlane32_swap), never
+//     from LDS.  The f16 product is only a SCREEN with a rigorous error bound err = 4.1e-3*S + 4e-7
+//     (S = sample peak seen so far): an output can be the maximum only if |approx| + err >= lb, where
+//     lb = max(S, max|approx| - err) is a proven lower bound of the true peak.  Those few candidates are
+//     re-evaluated exactly (f64 FMA chain in the oracle's tap order), so the reported peak is the exact
+//     f64 maximum over all outputs: bit-identical to the generic kernel and to the oracle.
+//
+// Rows cover hops 0 .. n_hops-2; the last hop and the ragged tail of every track (1/1800 of a 3-minute
+// track) go through the bounds-checked generic kernels, so this kernel needs no bounds checks at all.
+//
+// Replaces FFmpeg f_ebur128.c FILTER()/i400 accumulation and swr_convert + fabs max (reached from
+// src/analyzer.rs:253-267); SURVEY.md Appendix A.2 / A.4.
+#include <hip/hip_runtime.h>
+
+#include "hr_device.hpp"
+#include "hr_kernels.hpp"
+
+namespace hr {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+
+// Tables that no kernel writes are read through the constant address space, so that wave-uniform reads
+// become scalar loads (s_load) instead of 64 identical vector loads.
+typedef const __attribute__((address_space(4))) double *cdouble_p;
+typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
+
+constexpr int kWaveLds = 8192 + 9 * 1024;  // LDS bytes per wave
+
+constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
+constexpr float kScreenAbs = 4.0e-7f;  // f16 subnormal inputs / coefficients
+constexpr float kF16Safe = 60000.0f;   // above this |x| does not fit f16: everything becomes a candidate
+
+// Wave-wide maximum with DPP cross-lane moves only (no LDS round trips): quads, half rows, rows, then the
+// two row broadcasts; lane 63 ends up with the maximum of all 64 lanes.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_max(float v)
+{
+    const int o = __builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return fmaxf(v, __int_as_float(o));
+}
+
+__device__ __forceinline__ float wave_max_f32(float v)
+{
+    v = dpp_max<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_max<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_max<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_max<0x140, 0xf>(v);  // row_mirror
+    v = dpp_max<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_max<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+__device__ __forceinline__ double wave_max_f64(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ half8 as_half8(uint4v u)
+{
+    union { uint4v u; half8 h; } c;
+    c.u = u;
+    return c.h;
+}
+
+__device__ __forceinline__ unsigned pk_f16(float a, float b)
+{
+    const auto h = __builtin_amdgcn_cvt_pkrtz(a, b);  // round toward zero: |x - f16(x)| <= 2^-10 |x|
+    unsigned u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+
+// frame i (relative to the track start) of channel c, with start reflection / shard halos; exact path only
+__device__ __forceinline__ double fetch_f32s(const TrackDesc &t, int c, int64_t i)
+{
+    const int64_t N = static_cast<int64_t>(t.frames);
+    if (i < 0) {
+        if (t.left_tail) return (i >= -kHalo) ? t.left_tail[(kHalo + i) * 2 + c] : 0.0;
+        i = -i;
+    }
+    if (i >= N) {
+        if (t.right_head && i - N < kHalo) return t.right_head[(i - N) * 2 + c];
+        return 0.0;
+    }
+    return static_cast<double>(static_cast<const float *>(t.pcm)[i * 2 + c]);
+}
+
+// Exact re-evaluation of the flagged outputs of one accumulator tile.  Rare path.
+__device__ __noinline__ double refine_tile(const TrackDesc *tp, const double *__restrict__ taps, int P, int step,
+                                           int64_t row_frame0, int c, int m_lo, int count, int row_base,
+                                           floatx16 acc, float thr)
+{
+    const TrackDesc &t = *tp;
+    double best = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        if (!(fabsf(acc[i]) >= thr)) continue;
+        const int rowidx = row_base + (i & 3) + 8 * (i >> 2);
+        if (rowidx >= count) continue;
+        const int m = m_lo + rowidx;
+        const int u = (m * step) / P;
+        const int ph = m * step - u * P;
+        const int64_t pos = row_frame0 + u;
+        const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
+        double val = 0.0;
+        for (int k = 0; k < kSwrTaps; k++) val = fma(fetch_f32s(t, c, pos - 15 + k), f[k], val);
+        const double a = fabs(val);
+        best = a > best ? a : best;
+    }
+    return best;
+}
+
+struct KState {
+    double x1, x2, y1, y2, z1, z2, e0, q0, q1, q2, q3;
+};
+
+__device__ __forceinline__ void kw_sample(KState &s, const KCoef &k, float xf, cdouble_p g)
+{
+    const double x0 = static_cast<double>(xf);
+    double tt = k.pb0 * x0;
+    tt = fma(k.pb1, s.x1, tt);
+    tt = fma(k.pb2, s.x2, tt);
+    tt = fma(-k.pa2, s.y2, tt);
+    const double y0 = fma(-k.pa1, s.y1, tt);
+    double v = fma(-2.0, s.y1, y0);
+    v = v + s.y2;
+    v = fma(-k.ra2, s.z2, v);
+    const double z0 = fma(-k.ra1, s.z1, v);
+    s.e0 = fma(z0, z0, s.e0);
+    s.q0 = fma(z0, g[0], s.q0);
+    s.q1 = fma(z0, g[1], s.q1);
+    s.q2 = fma(z0, g[2], s.q2);
+    s.q3 = fma(z0, g[3], s.q3);
+    s.x2 = s.x1; s.x1 = x0;
+    s.y2 = s.y1; s.y1 = y0;
+    s.z2 = s.z1; s.z1 = z0;
+}
+
+template <bool DO_KW, bool DO_TP>
+__global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restrict__ tracks,
+                                                       const RateDev *__restrict__ rates,
+                                                       const FusedItem *__restrict__ items, uint32_t n_items,
+                                                       HopRec *__restrict__ recs,
+                                                       unsigned long long *__restrict__ peaks, int dbg)
+{
+    // dbg (timing experiments only, results are wrong when set): 1 = never refine, 2 = no coefficient DMA,
+    // 4 = no MFMA screen, 8 = no bound updates
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 waves x (8 KiB pieces + 9 KiB coefficient tiles)
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t item_idx = blockIdx.x * 4 + wave;
+    if (item_idx >= n_items) return;  // whole wave leaves; no workgroup barrier is used in this kernel
+    const FusedItem it = items[item_idx];
+    const TrackDesc &t = tracks[it.track];
+    const RateDev &r = rates[t.rate_idx];
+    const KCoef kc = r.k;
+    const uint32_t hop = t.hop;
+    const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
+    const int n_rows = static_cast<int>(it.n_rows);
+    const int row = lane < n_rows ? lane : n_rows - 1;  // idle lanes shadow the last row
+    const uint64_t h = it.first_hop + row;
+    const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * 8ull;
+    char *lbuf = smem + wave * kWaveLds;
+    char *abuf = lbuf + 8192;
+    cdouble_p g = (cdouble_p)r.g;
+    const int T_full = static_cast<int>(hop / 16), rem = static_cast<int>(hop % 16);
+
+    // ---- DMA geometry: instruction j moves LDS slots 8j..8j+7 (one 128-byte piece each, 8 lanes per piece)
+    unsigned dma_off[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int slot = 8 * j + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((slot >> 1) & 7);
+        const int srow = slot < n_rows ? slot : n_rows - 1;
+        dma_off[j] = static_cast<unsigned>(srow) * hop * 8u + static_cast<unsigned>(chunk) * 16u;
+    }
+    const unsigned rd_swz = (lane >> 1) & 7;
+    const char *my_lds = lbuf + lane * 128;
+
+    // ---- prologue: the 16 frames in front of the row (FIR window of tile 0, filter input history)
+    float4 v[8];
+    KState ks[2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) ks[c] = KState{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    {
+        const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * 8u);
+        if (h > 0) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(rowp - 32 + 4 * c);
+            ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
+            ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
+        } else if (t.left_tail) {
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                v[c] = make_float4(static_cast<float>(t.left_tail[(2 * c) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c) * 2 + 1]),
+                                   static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 1]));
+            ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
+            ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
+        } else {
+            // start of the stream: libswresample reflects, x[-j] = x[j]; the K-weighting starts from silence
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float2 a = *reinterpret_cast<const float2 *>(rowp + 2 * (16 - 2 * c));
+                const float2 b = *reinterpret_cast<const float2 *>(rowp + 2 * (15 - 2 * c));
+                v[c] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+    }
+
+    // signal fragments of the three newest pieces: [age][channel][n-tile]
+    uint4v hist[3][2][2];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) hist[a][c][n] = uint4v{0, 0, 0, 0};
+
+    // per channel: the peak is reported per channel, so every bound is per channel too
+    float s_lane[2] = {0.0f, 0.0f};  // max |x| this lane has seen (exact)
+    float alb[2] = {0.0f, 0.0f};     // max |approx output| this lane has seen
+    float lb[2] = {0.0f, 0.0f};      // wave-uniform proven lower bound of the channel's true peak
+    double best[2] = {0.0, 0.0};     // exact maxima found by refinement
+
+    auto make_frags = [&](int age) {
+        if constexpr (DO_TP) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
+                s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
+            }
+            unsigned f[2][8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                f[0][c] = pk_f16(v[c].x, v[c].z);
+                f[1][c] = pk_f16(v[c].y, v[c].w);
+            }
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const auto sw = __builtin_amdgcn_permlane32_swap(f[ch][j], f[ch][j + 4], false, false);
+                    hist[age][ch][0][j] = sw[0];
+                    hist[age][ch][1][j] = sw[1];
+                }
+        }
+    };
+    make_frags(2);  // the prologue piece is "piece -1"
+
+    // tile bookkeeping (wave-uniform): outputs m_lo .. m_lo+count-1 belong to tile t
+    const int P = r.swr_phases, step = r.swr_step;
+    const int NP = r.tp_np, MT = r.tp_mt;
+    const int q16 = (16 * P) / step, r16 = (16 * P) % step;
+    int tq = 0, tr = 0;   // floor and remainder of 16*t*P/step for the tile being screened
+    int pat = 0;
+
+    // first piece
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wave_base + dma_off[j]),
+                                         (__attribute__((address_space(3))) void *)(lbuf + j * 1024), 16, 0, 0);
+
+    // coefficient tiles of tile 0
+    if constexpr (DO_TP) {
+        const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + lane * 16;
+        for (int i = 0; i < 3 * MT; i++)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + i * 1024),
+                                             (__attribute__((address_space(3))) void *)(abuf + i * 1024), 16, 0, 0);
+    }
+
+    for (int k = 0; k <= T; k++) {
+        // ---- piece k has landed?  (everything this wave has in flight: the DMA and the A fragments)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(my_lds + ((c ^ rd_swz) * 16));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        // the last piece of a hop may be partial (44.1 kHz: 4410 = 275*16 + 10): K-weight its frames one at a
+        // time straight from LDS, before the buffer is handed back to the DMA
+        if (DO_KW && rem && k == T_full) {
+            cdouble_p gk = g + static_cast<size_t>(k) * 64;
+            for (int i = 0; i < rem; i++) {
+                const float2 x = *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8);
+                kw_sample(ks[0], kc, x.x, gk + i * 4);
+                kw_sample(ks[1], kc, x.y, gk + i * 4);
+            }
+        }
+        // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
+        if (k < T) {
+            const char *src = wave_base + static_cast<size_t>(k + 1) * 128;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + dma_off[j]),
+                                                 (__attribute__((address_space(3))) void *)(lbuf + j * 1024), 16, 0, 0);
+        }
+        // rotate the fragment history and append piece k
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) {
+                hist[0][c][n] = hist[1][c][n];
+                hist[1][c][n] = hist[2][c][n];
+            }
+        make_frags(2);
+
+        // ---- K3: screen tile k-1 (pieces k-2, k-1, k)
+        if (DO_TP && k >= 1) {
+            const int m_lo = tq + (tr > 0);
+            int nq = tq + q16, nr = tr + r16;
+            if (nr >= step) { nr -= step; nq++; }
+            const int count = (nq + (nr > 0)) - m_lo;
+            // error bound of this tile's approximations and candidate threshold, per channel.  S covers every
+            // frame of the tile's window (it includes piece k), so err bounds |approx - exact| for all outputs
+            // screened so far; lb is a proven lower bound of the true peak, so an output below lb - err cannot
+            // be the maximum.  S itself is a valid lb: phase 0 of the bank passes the samples through.
+            float S[2], err[2], thr[2];
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                S[ch] = wave_max_f32(s_lane[ch]);
+                err[ch] = S[ch] < kF16Safe ? fmaf(kScreenRel, S[ch], kScreenAbs) : __builtin_inff();
+                lb[ch] = fmaxf(lb[ch], S[ch]);
+                thr[ch] = S[ch] < kF16Safe ? lb[ch] - err[ch] : -1.0f;
+            }
+            unsigned flags = 0;  // bit (mt*4 + ch*2 + nt): this lane holds a candidate in that accumulator
+#pragma unroll
+            for (int mt = 0; mt < 3; mt++) {
+                if (mt >= MT || (dbg & 4)) continue;
+                uint4v af[3];
+#pragma unroll
+                for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + (mt * 3 + k3) * 1024 + lane * 16);
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        floatx16 acc = {0};
+#pragma unroll
+                        for (int k3 = 0; k3 < 3; k3++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
+                        float m0 = 0.0f;
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) m0 = fmaxf(fmaxf(fabsf(acc[i]), fabsf(acc[i + 1])), m0);
+                        alb[ch] = fmaxf(alb[ch], m0);
+                        if ((m0 >= thr[ch]) && (m0 > 0.0f || thr[ch] < 0.0f)) flags |= 1u << (mt * 4 + ch * 2 + nt);
+                    }
+            }
+            const bool refined = !(dbg & 1) && __ballot(flags != 0) != 0ull;
+            if (refined) {
+                // rare: recompute the flagged accumulators and evaluate their candidates exactly (f64)
+#pragma unroll 1
+                for (int mt = 0; mt < MT; mt++) {
+                    if (__ballot((flags >> (mt * 4)) & 15u) == 0ull) continue;
+                    uint4v af[3];
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + (mt * 3 + k3) * 1024 + lane * 16);
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                        for (int nt = 0; nt < 2; nt++) {
+                            const bool flag = (flags >> (mt * 4 + ch * 2 + nt)) & 1u;
+                            if (__ballot(flag) == 0ull) continue;
+                            floatx16 acc = {0};
+#pragma unroll
+                            for (int k3 = 0; k3 < 3; k3++)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
+                            if (flag) {
+                                // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31)
+                                int crow = 32 * nt + (lane & 31);
+                                crow = crow < n_rows ? crow : n_rows - 1;
+                                const double b = refine_tile(&t, r.swr_taps, P, step, static_cast<int64_t>(it.first_hop + crow) * hop,
+                                                             ch, m_lo, count, 32 * mt + 4 * (lane >> 5), acc, thr[ch]);
+                                best[ch] = b > best[ch] ? b : best[ch];
+                            }
+                        }
+                }
+            }
+            // new proven lower bounds for the next tile
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++) {
+                if (dbg & 8) continue;
+                const float A = wave_max_f32(alb[ch]);
+                lb[ch] = fmaxf(lb[ch], A - err[ch]);
+                if (refined) lb[ch] = fmaxf(lb[ch], __double2float_rz(wave_max_f64(best[ch])));
+            }
+            tq = nq;
+            tr = nr;
+            pat = pat + 1 == NP ? 0 : pat + 1;
+        }
+
+        // ---- the next tile's coefficient tiles (this tile's LDS reads are done)
+        if (DO_TP && k < T && !(dbg & 2)) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + static_cast<size_t>(pat) * MT * 3 * 1024 + lane * 16;
+            for (int i = 0; i < 3 * MT; i++)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + i * 1024),
+                                                 (__attribute__((address_space(3))) void *)(abuf + i * 1024), 16, 0, 0);
+        }
+
+        // ---- K1/K2a: K-weight the 16 frames of piece k
+        if (DO_KW && k < T_full) {
+            cdouble_p gk = g + static_cast<size_t>(k) * 64;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                kw_sample(ks[0], kc, v[c].x, gk + (2 * c) * 4);
+                kw_sample(ks[1], kc, v[c].y, gk + (2 * c) * 4);
+                kw_sample(ks[0], kc, v[c].z, gk + (2 * c + 1) * 4);
+                kw_sample(ks[1], kc, v[c].w, gk + (2 * c + 1) * 4);
+            }
+        }
+    }
+
+    if (DO_KW && lane < n_rows) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            HopRec &o = recs[t.rec_base + (kPreRec + h) * 2 + c];
+            o.e0 = ks[c].e0;
+            o.q[0] = ks[c].q0; o.q[1] = ks[c].q1; o.q[2] = ks[c].q2; o.q[3] = ks[c].q3;
+            o.s[0] = ks[c].y1; o.s[1] = ks[c].y1 - ks[c].y2; o.s[2] = ks[c].z1; o.s[3] = ks[c].z1 - ks[c].z2;
+        }
+    }
+    if constexpr (DO_TP) {
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            const double bm = wave_max_f64(best[c]);
+            if (lane == 0 && bm > 0.0)
+                atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c], static_cast<unsigned long long>(__double_as_longlong(bm)));
+        }
+    }
+}
+
+void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
+                       HopRec *recs, unsigned long long *peaks, int variant, hipStream_t st)
+{
+    launch_fused_f32s_dbg(tracks, rates, items, n_items, recs, peaks, variant, 0, st);
+}
+
+void launch_fused_f32s_dbg(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
+                           HopRec *recs, unsigned long long *peaks, int variant, int dbg, hipStream_t st)
+{
+    if (!n_items) return;
+    const dim3 grid((n_items + 3) / 4), block(256);
+    const size_t lds = 4 * kWaveLds;
+    switch (variant) {
+    case 1: k_fused_f32s<true, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
+    case 2: k_fused_f32s<false, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
+    case 3: k_fused_f32s<false, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
+    default: k_fused_f32s<true, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
+    }
+}
+
+}  // namespace hr

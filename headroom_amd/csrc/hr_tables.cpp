@@ -8,7 +8,9 @@
 //   histogram energies  f_ebur128.c init(); libavfilter/ebur128.c histogram_init()
 #include "hr_tables.hpp"
 
+#include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -103,6 +105,69 @@ static void build_swr(RateTables &rt)
     }
 }
 
+uint16_t f32_to_f16_rn(float f)
+{
+    uint32_t x;
+    std::memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000u;
+    const uint32_t absx = x & 0x7fffffffu;
+    if (absx >= 0x7f800000u) return static_cast<uint16_t>(sign | 0x7c00u | ((absx > 0x7f800000u) ? 0x200u : 0));
+    if (absx >= 0x477ff000u) return static_cast<uint16_t>(sign | 0x7c00u);  // rounds to infinity
+    if (absx < 0x38800000u) {  // subnormal half (or zero): value = m * 2^-24
+        if (absx < 0x33000000u) return static_cast<uint16_t>(sign);  // < 2^-25: rounds to zero
+        const int e = static_cast<int>(absx >> 23);                  // biased exponent, 102..112
+        const uint32_t mant = (absx & 0x7fffffu) | 0x800000u;        // 24-bit significand
+        const int shift = 126 - e;                                   // 14..24 bits to drop
+        uint32_t m = mant >> shift;
+        const uint32_t rem = mant & ((1u << shift) - 1), half = 1u << (shift - 1);
+        if (rem > half || (rem == half && (m & 1))) m++;
+        return static_cast<uint16_t>(sign | m);
+    }
+    uint32_t m = absx - 0x38000000u;  // rebias exponent by 112
+    const uint32_t rem = m & 0x1fffu;
+    m >>= 13;
+    if (rem > 0x1000u || (rem == 0x1000u && (m & 1))) m++;
+    return static_cast<uint16_t>(sign | m);
+}
+
+static void build_tp_tiles(RateTables &rt)
+{
+    const int P = rt.swr_phases, step = rt.swr_step;
+    if (P <= 0) return;
+    int g = 16, b = step;
+    while (b) { const int tmp = g % b; g = b; b = tmp; }
+    const int NP = step / g;
+    // outputs per 16-frame tile, largest over the NP tile patterns
+    long max_out = 0;
+    for (int p = 0; p < NP; p++)
+        max_out = std::max(max_out, (16L * (p + 1) * P + step - 1) / step - (16L * p * P + step - 1) / step);
+    const int MT = static_cast<int>((max_out + 31) / 32);
+    if (MT > 3) return;  // low sample rates (many phases per input frame) stay on the generic kernel
+    rt.tp_np = NP;
+    rt.tp_mt = MT;
+    rt.tp_atab.assign(static_cast<size_t>(NP) * MT * 3 * 64 * 8, 0);
+    for (int p = 0; p < NP; p++) {
+        const long m_lo = (16L * p * P + step - 1) / step;
+        const long m_hi = (16L * (p + 1) * P + step - 1) / step;
+        for (int mt = 0; mt < MT; mt++)
+            for (int ks = 0; ks < 3; ks++)
+                for (int lane = 0; lane < 64; lane++)
+                    for (int i = 0; i < 8; i++) {
+                        const long m = m_lo + 32 * mt + (lane & 31);
+                        const int kappa = 16 * ks + 8 * (lane >> 5) + i;  // window frame index, window = tile frames -16 .. +31
+                        double v = 0.0;
+                        if (m < m_hi) {
+                            const long u = m * step / P - 16L * p;      // position inside the tile, 0..15
+                            const int ph = static_cast<int>(m * step % P);
+                            const int tap = kappa - 1 - static_cast<int>(u);  // output uses frames pos-15 .. pos+16
+                            if (tap >= 0 && tap < kSwrTaps) v = rt.swr_taps[static_cast<size_t>(ph) * kSwrTaps + tap];
+                        }
+                        rt.tp_atab[((((static_cast<size_t>(p) * MT + mt) * 3 + ks) * 64) + lane) * 8 + i] =
+                            f32_to_f16_rn(static_cast<float>(v));
+                    }
+    }
+}
+
 static void matmul4(const long double *a, const long double *b, long double *c)
 {
     for (int i = 0; i < 4; i++)
@@ -169,6 +234,7 @@ const RateTables *rate_tables(uint32_t fs)
     rt->k = kweight_coeffs(static_cast<double>(fs));
     build_carry(*rt);
     build_swr(*rt);
+    build_tp_tiles(*rt);
     const RateTables *p = rt.get();
     cache[fs] = std::move(rt);
     return p;

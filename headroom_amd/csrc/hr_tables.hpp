@@ -34,6 +34,12 @@ struct RateTables {
     int swr_phases = 0, swr_step = 0;
     std::vector<double> swr_taps;  // [(phases+1)][32]
     double swr_l1 = 0;             // max over phases of sum |tap|
+    // f16 coefficient tiles of the MFMA true-peak screen (hr_kernels_fused.hip): one tile of 16 input
+    // positions produces the outputs m with floor(m*step/P) in the tile from a 48-frame window; the
+    // output pattern repeats every tp_np tiles.  Layout [tp_np][tp_mt][3 k-steps][64 lanes][8 halfs]:
+    // the A fragments of v_mfma_f32_32x32x16_f16 (lane l: row 32*mt + (l&31), k = 16*ks + 8*(l>>5) + i).
+    std::vector<uint16_t> tp_atab;
+    int tp_np = 0, tp_mt = 0;
 };
 
 // Builds (and caches per process) the tables of one rate.  Returns nullptr for fs < 10.
@@ -49,5 +55,7 @@ const std::vector<double> &loudnorm_bin_energy();
 const std::vector<double> &loudnorm_bin_bounds();
 
 void default_weights(int channels, float *w);
+
+uint16_t f32_to_f16_rn(float f);
 
 }  // namespace hr

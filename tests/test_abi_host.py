@@ -134,3 +134,13 @@ def test_cpu_carry_algebra(oracle):
                            "-Wl,-rpath," + os.path.dirname(oracle.LIB_PATH)])
     for args in (("48000", "2", "1", "0"), ("44100", "2", "2", "1"), ("96000", "1", "3", "2")):
         subprocess.check_call([exe, *args], stdout=subprocess.DEVNULL)
+
+
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_tp_screen_tiles_and_error_bound(fs):
+    """f16 coefficient tiles of the MFMA true-peak screen: every output of every tile is reproduced within
+    the screen's error bound, and the host f32->f16 conversion rounds to nearest even."""
+    exe = "/tmp/hr_tp_tiles_check"
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", os.path.join(ROOT, "tests", "cpu_tp_tiles_check.cpp"),
+                           os.path.join(ROOT, "headroom_amd", "csrc", "hr_tables.cpp"), "-o", exe])
+    subprocess.check_call([exe, str(fs)], stdout=subprocess.DEVNULL)
