@@ -75,11 +75,13 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
 
     // workspace (grow-only)
-    DevBuf tracks_d, items_d, fitems_d, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
     std::vector<FusedItem> h_fitems;
+    std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
+    std::vector<WorkItem> h_ovf_items;
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -292,6 +294,21 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     const WorkItem *di = ctx->items_d.as<WorkItem>();
 
+    FusedScratch fs{};
+    if (!fitems.empty()) {
+        if (!ctx->cands.ensure(fused_cand_bytes(static_cast<uint32_t>(fitems.size()))) ||
+            !ctx->cand_cnt.ensure(fitems.size() * sizeof(unsigned)) || !ctx->tpb.ensure(nt * kMaxCh * 2 * sizeof(unsigned)) ||
+            !ctx->overflow.ensure(nt * sizeof(unsigned)))
+            return HR_ERR_OOM;
+        fs.cands = ctx->cands.p;
+        fs.cand_cnt = ctx->cand_cnt.as<unsigned>();
+        fs.tpb = ctx->tpb.as<unsigned>();
+        fs.overflow = ctx->overflow.as<unsigned>();
+        HIPCHK(hipMemsetAsync(ctx->tpb.p, 0, nt * kMaxCh * 2 * sizeof(unsigned), st));
+        HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
+    }
+    ctx->h_ftp.assign(ftp.begin(), ftp.end());
+
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
@@ -299,10 +316,15 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
         // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
         const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
-        launch_fused_f32s_dbg(dt, dr, fi, static_cast<uint32_t>(fused_split), ctx->recs.as<HopRec>(),
-                              ctx->peaks.as<unsigned long long>(), v0, dbg, st);
-        launch_fused_f32s_dbg(dt, dr, fi + fused_split, static_cast<uint32_t>(fitems.size() - fused_split),
-                              ctx->recs.as<HopRec>(), ctx->peaks.as<unsigned long long>(), v0 == 3 ? 3 : 1, dbg, st);
+        launch_fused_f32s(dt, dr, fi, static_cast<uint32_t>(fused_split), ctx->recs.as<HopRec>(), fs,
+                          ctx->peaks.as<unsigned long long>(), v0, dbg, st);
+        FusedScratch fs2 = fs;
+        if (fs2.cands) {
+            fs2.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(fused_split));
+            fs2.cand_cnt = fs.cand_cnt + fused_split;
+        }
+        launch_fused_f32s(dt, dr, fi + fused_split, static_cast<uint32_t>(fitems.size() - fused_split), ctx->recs.as<HopRec>(),
+                          fs2, ctx->peaks.as<unsigned long long>(), v0 == 3 ? 3 : 1, dbg, st);
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     for (int f = 0; f < 5; f++)
@@ -372,6 +394,50 @@ void fill_result(const hr_ctx *ctx, const TrackOut &o, const unsigned long long 
     r->status = HR_OK;
 }
 
+// A wave of the fused kernel ran out of candidate slots (or met samples beyond the f16 range): the track's
+// fused positions are redone with the generic f64 kernel.  Synchronises the stream.  Expected never to
+// trigger on audio; it keeps the exactness guarantee unconditional.
+int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nt = g.descs.size();
+    bool any_fused = false;
+    for (size_t i = 0; i < nt && i < ctx->h_ftp.size(); i++) any_fused |= ctx->h_ftp[i] != 0;
+    if (!any_fused) return HR_OK;
+    std::vector<unsigned> ovf(nt);
+    HIPCHK(hipMemcpyAsync(ovf.data(), ctx->overflow.p, nt * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<WorkItem> &items = ctx->h_ovf_items;
+    items.clear();
+    for (size_t i = 0; i < nt; i++) {
+        if (!ctx->h_ftp[i] || !ovf[i]) continue;
+        const uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
+        for (uint64_t n = 0; n < end; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
+    }
+    if (std::getenv("HR_DEBUG")) {
+        std::vector<unsigned> cnt(ctx->h_fitems.size());
+        (void)hipMemcpy(cnt.data(), ctx->cand_cnt.p, cnt.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
+        unsigned long long tot = 0, mx = 0, full = 0, novf = 0;
+        for (unsigned c : cnt) { tot += c; mx = std::max<unsigned long long>(mx, c); full += c >= 512; }
+        for (unsigned o : ovf) novf += o != 0;
+        for (size_t i = 0, shown = 0; i < cnt.size() && shown < 12; i++)
+            if (cnt[i] >= 512) { std::fprintf(stderr, "  full list: track %u first_hop %llu rows %u\n", ctx->h_fitems[i].track, (unsigned long long)ctx->h_fitems[i].first_hop, ctx->h_fitems[i].n_rows); shown++; }
+        for (size_t i = 0; i < 29 && i < cnt.size(); i++) std::fprintf(stderr, " %u", cnt[i]);
+        std::fprintf(stderr, "\n");
+        std::fprintf(stderr, "headroom_hip: fused waves %zu, candidates total %llu (mean %.1f, max %llu, full lists %llu), overflowed tracks %llu of %zu\n",
+                     cnt.size(), tot, cnt.empty() ? 0.0 : double(tot) / cnt.size(), mx, full, novf, nt);
+    }
+    if (items.empty()) return HR_OK;
+    // the last item of a track may reach a little past `end`: those positions are redone too, harmlessly
+    int rc = upload(ctx->ovf_items, items.data(), items.size() * sizeof(WorkItem), st);
+    if (rc) return rc;
+    launch_true_peak_generic(HR_FMT_F32, HR_TP_SWR192K, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(),
+                             ctx->bs_taps.as<double>(), ctx->ovf_items.as<WorkItem>(), static_cast<uint32_t>(items.size()),
+                             kPeakSpan, ctx->peaks.as<unsigned long long>(), st);
+    HIPCHK(hipGetLastError());
+    return HR_OK;
+}
+
 // Stages the host-resident tracks of [begin, end) and measures the group.
 int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t> &idx, hr_result *out)
 {
@@ -404,6 +470,8 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     rc = run_gating(ctx, g, true);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
+    rc = redo_overflowed_peaks(ctx, g);
+    if (rc) return rc;
     const size_t nt = g.descs.size();
     std::vector<TrackOut> outs(nt);
     std::vector<unsigned long long> pk(nt * kMaxCh);
@@ -466,7 +534,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
-                      &ctx->items_d, &ctx->fitems_d, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -703,6 +771,8 @@ int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *par
     launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->items_d.as<WorkItem>() + ctx->comb_off,
                        static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), st);
     int rc = run_gating(ctx, g, false);
+    if (rc) return rc;
+    rc = redo_overflowed_peaks(ctx, g);
     if (rc) return rc;
     std::vector<uint32_t> hist(kEbuBins);
     TrackOut o{};

@@ -23,12 +23,16 @@ void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, con
                               unsigned long long *peaks, hipStream_t st);
 
 // hr_kernels_fused.hip: stereo f32, swr true peak.  variant 0 = full; 1 = K-weight only, 2 = true peak only,
-// 3 = data movement only (ablation builds for the roofline analysis)
+// 3 = data movement only (ablation builds for the roofline analysis); dbg: timing-only switches, 0 in production.
+struct FusedScratch {
+    void *cands;         // fused_cand_bytes(n_items): per-wave candidate lists
+    unsigned *cand_cnt;  // [n_items]
+    unsigned *tpb;       // [n_tracks][kMaxCh][2]: final lower bound / sample peak per channel (float bits), zeroed per call
+    unsigned *overflow;  // [n_tracks]: a wave's list overflowed -> the track's peak must be redone generically, zeroed per call
+};
+size_t fused_cand_bytes(uint32_t n_items);
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
-                       HopRec *recs, unsigned long long *peaks, int variant, hipStream_t st);
-
-void launch_fused_f32s_dbg(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
-                           HopRec *recs, unsigned long long *peaks, int variant, int dbg, hipStream_t st);
+                       HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int dbg, hipStream_t st);
 
 // hr_synth.hip
 struct SynthPar {

@@ -18,8 +18,10 @@
 //     from LDS.  The f16 product is only a SCREEN with a rigorous error bound err = 4.1e-3*S + 4e-7
 //     (S = sample peak seen so far): an output can be the maximum only if |approx| + err >= lb, where
 //     lb = max(S, max|approx| - err) is a proven lower bound of the true peak.  Those few candidates are
-//     re-evaluated exactly (f64 FMA chain in the oracle's tap order), so the reported peak is the exact
-//     f64 maximum over all outputs: bit-identical to the generic kernel and to the oracle.
+//     appended to a per-wave list (no atomics, no waiting) and k_refine_cands re-evaluates the ones that
+//     still matter against the track's final bound exactly (f64 FMA chain in the oracle's tap order), so
+//     the reported peak is the exact f64 maximum over all outputs: bit-identical to the generic kernel and
+//     to the oracle.  A wave whose list overflows flags its track, which then takes the generic kernel.
 //
 // Rows cover hops 0 .. n_hops-2; the last hop and the ragged tail of every track (1/1800 of a 3-minute
 // track) go through the bounds-checked generic kernels, so this kernel needs no bounds checks at all.
@@ -43,6 +45,7 @@ typedef const __attribute__((address_space(4))) double *cdouble_p;
 typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 
 constexpr int kWaveLds = 8192 + 9 * 1024;  // LDS bytes per wave
+constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
 
 constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
 constexpr float kScreenAbs = 4.0e-7f;  // f16 subnormal inputs / coefficients
@@ -108,29 +111,27 @@ __device__ __forceinline__ double fetch_f32s(const TrackDesc &t, int c, int64_t 
     return static_cast<double>(static_cast<const float *>(t.pcm)[i * 2 + c]);
 }
 
-// Exact re-evaluation of the flagged outputs of one accumulator tile.  Rare path.
-__device__ __noinline__ double refine_tile(const TrackDesc *tp, const double *__restrict__ taps, int P, int step,
-                                           int64_t row_frame0, int c, int m_lo, int count, int row_base,
-                                           floatx16 acc, float thr)
+// One interpolated output, exactly: f64 FMA chain over the 32 taps in the oracle's order.
+__device__ __forceinline__ double exact_output(const TrackDesc &t, const double *__restrict__ taps, int P, int step,
+                                               int64_t row_frame0, int c, int m)
 {
-    const TrackDesc &t = *tp;
-    double best = 0.0;
+    const int u = (m * step) / P;
+    const int ph = m * step - u * P;
+    const int64_t pos = row_frame0 + u;
+    const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
+    double x[kSwrTaps];
+    if (pos >= 15 && pos + 16 < static_cast<int64_t>(t.frames)) {
+        const float *p = static_cast<const float *>(t.pcm) + (pos - 15) * 2 + c;
 #pragma unroll
-    for (int i = 0; i < 16; i++) {
-        if (!(fabsf(acc[i]) >= thr)) continue;
-        const int rowidx = row_base + (i & 3) + 8 * (i >> 2);
-        if (rowidx >= count) continue;
-        const int m = m_lo + rowidx;
-        const int u = (m * step) / P;
-        const int ph = m * step - u * P;
-        const int64_t pos = row_frame0 + u;
-        const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
-        double val = 0.0;
-        for (int k = 0; k < kSwrTaps; k++) val = fma(fetch_f32s(t, c, pos - 15 + k), f[k], val);
-        const double a = fabs(val);
-        best = a > best ? a : best;
+        for (int k = 0; k < kSwrTaps; k++) x[k] = static_cast<double>(p[2 * k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kSwrTaps; k++) x[k] = fetch_f32s(t, c, pos - 15 + k);
     }
-    return best;
+    double val = 0.0;
+#pragma unroll
+    for (int k = 0; k < kSwrTaps; k++) val = fma(x[k], f[k], val);
+    return fabs(val);
 }
 
 struct KState {
@@ -163,7 +164,9 @@ template <bool DO_KW, bool DO_TP>
 __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restrict__ tracks,
                                                        const RateDev *__restrict__ rates,
                                                        const FusedItem *__restrict__ items, uint32_t n_items,
-                                                       HopRec *__restrict__ recs,
+                                                       HopRec *__restrict__ recs, uint2 *__restrict__ cands,
+                                                       unsigned *__restrict__ cand_cnt, unsigned *__restrict__ tpb,
+                                                       unsigned *__restrict__ overflow,
                                                        unsigned long long *__restrict__ peaks, int dbg)
 {
     // dbg (timing experiments only, results are wrong when set): 1 = never refine, 2 = no coefficient DMA,
@@ -243,7 +246,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     float s_lane[2] = {0.0f, 0.0f};  // max |x| this lane has seen (exact)
     float alb[2] = {0.0f, 0.0f};     // max |approx output| this lane has seen
     float lb[2] = {0.0f, 0.0f};      // wave-uniform proven lower bound of the channel's true peak
-    double best[2] = {0.0, 0.0};     // exact maxima found by refinement
+    unsigned n_cand = 0;             // wave-uniform: candidates appended so far
+    uint2 *__restrict__ my_cands = cands + static_cast<size_t>(item_idx) * kCandCap;
 
     auto make_frags = [&](int age) {
         if constexpr (DO_TP) {
@@ -365,9 +369,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                         if ((m0 >= thr[ch]) && (m0 > 0.0f || thr[ch] < 0.0f)) flags |= 1u << (mt * 4 + ch * 2 + nt);
                     }
             }
-            const bool refined = !(dbg & 1) && __ballot(flags != 0) != 0ull;
-            if (refined) {
-                // rare: recompute the flagged accumulators and evaluate their candidates exactly (f64)
+            if (!(dbg & 1) && __ballot(flags != 0) != 0ull) {
+                // rare: recompute the flagged accumulators and append their candidate outputs to the wave's list
 #pragma unroll 1
                 for (int mt = 0; mt < MT; mt++) {
                     if (__ballot((flags >> (mt * 4)) & 15u) == 0ull) continue;
@@ -384,13 +387,24 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
                             for (int k3 = 0; k3 < 3; k3++)
                                 acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
-                            if (flag) {
-                                // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31)
-                                int crow = 32 * nt + (lane & 31);
-                                crow = crow < n_rows ? crow : n_rows - 1;
-                                const double b = refine_tile(&t, r.swr_taps, P, step, static_cast<int64_t>(it.first_hop + crow) * hop,
-                                                             ch, m_lo, count, 32 * mt + 4 * (lane >> 5), acc, thr[ch]);
-                                best[ch] = b > best[ch] ? b : best[ch];
+                            // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31)
+                            // (columns past n_rows shadow the last row: never appended)
+                            const int crow = 32 * nt + (lane & 31);
+                            const int row_base = 32 * mt + 4 * (lane >> 5);
+#pragma unroll
+                            for (int i = 0; i < 16; i++) {
+                                const float a = fabsf(acc[i]);
+                                const int rowidx = row_base + (i & 3) + 8 * (i >> 2);
+                                const bool c = flag && crow < n_rows && a >= thr[ch] && (a > 0.0f || thr[ch] < 0.0f) && rowidx < count;
+                                const unsigned long long mask = __ballot(c);
+                                if (mask == 0ull) continue;
+                                const unsigned slot = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0));
+                                if (c && slot < kCandCap)
+                                    my_cands[slot] = make_uint2(static_cast<unsigned>(ch) | static_cast<unsigned>(crow) << 1 |
+                                                                    static_cast<unsigned>(m_lo + rowidx) << 7,
+                                                                __float_as_uint(a));
+                                n_cand += static_cast<unsigned>(__popcll(mask));
                             }
                         }
                 }
@@ -401,7 +415,6 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 if (dbg & 8) continue;
                 const float A = wave_max_f32(alb[ch]);
                 lb[ch] = fmaxf(lb[ch], A - err[ch]);
-                if (refined) lb[ch] = fmaxf(lb[ch], __double2float_rz(wave_max_f64(best[ch])));
             }
             tq = nq;
             tr = nr;
@@ -440,33 +453,70 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         }
     }
     if constexpr (DO_TP) {
+        // hand the wave's list and bounds over to k_refine_cands (next kernel on the stream)
+        float Sf[2];
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
-            const double bm = wave_max_f64(best[c]);
-            if (lane == 0 && bm > 0.0)
-                atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c], static_cast<unsigned long long>(__double_as_longlong(bm)));
+        for (int c = 0; c < 2; c++) Sf[c] = wave_max_f32(s_lane[c]);
+        if (lane == 0) {
+            cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
+            if (n_cand > kCandCap || Sf[0] >= kF16Safe || Sf[1] >= kF16Safe) overflow[it.track] = 1u;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                // non-negative floats order like their bit patterns
+                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(fmaxf(lb[c], Sf[c])));
+                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(Sf[c]));
+                // phase-0 outputs are the samples themselves: exact, and not part of the screen
+                if (Sf[c] > 0.0f)
+                    atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
+                              static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(Sf[c]))));
+            }
         }
     }
 }
 
-void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
-                       HopRec *recs, unsigned long long *peaks, int variant, hipStream_t st)
+// Exact evaluation of the candidates that can still be the maximum.  One workgroup per wave item of the
+// fused kernel, one thread per candidate slot.
+__global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__restrict__ tracks,
+                                                          const RateDev *__restrict__ rates,
+                                                          const FusedItem *__restrict__ items,
+                                                          const uint2 *__restrict__ cands,
+                                                          const unsigned *__restrict__ cand_cnt,
+                                                          const unsigned *__restrict__ tpb,
+                                                          unsigned long long *__restrict__ peaks)
 {
-    launch_fused_f32s_dbg(tracks, rates, items, n_items, recs, peaks, variant, 0, st);
+    const unsigned n = cand_cnt[blockIdx.x];
+    if (threadIdx.x >= n) return;
+    const FusedItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    const RateDev &r = rates[t.rate_idx];
+    const uint2 e = cands[static_cast<size_t>(blockIdx.x) * kCandCap + threadIdx.x];
+    const int ch = e.x & 1u, crow = (e.x >> 1) & 63u, m = static_cast<int>(e.x >> 7);
+    const float lbf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 0]);
+    const float Sf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 1]);
+    const float err = fmaf(kScreenRel, Sf, kScreenAbs);  // >= the bound that held when the candidate was screened
+    if (__uint_as_float(e.y) + err < lbf) return;        // cannot reach the track's proven lower bound
+    const double a = exact_output(t, r.swr_taps, r.swr_phases, r.swr_step, static_cast<int64_t>(it.first_hop + crow) * t.hop, ch, m);
+    if (a > 0.0)
+        atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + ch], static_cast<unsigned long long>(__double_as_longlong(a)));
 }
 
-void launch_fused_f32s_dbg(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
-                           HopRec *recs, unsigned long long *peaks, int variant, int dbg, hipStream_t st)
+size_t fused_cand_bytes(uint32_t n_items) { return static_cast<size_t>(n_items) * kCandCap * sizeof(uint2); }
+
+void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
+                       HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int dbg, hipStream_t st)
 {
     if (!n_items) return;
     const dim3 grid((n_items + 3) / 4), block(256);
     const size_t lds = 4 * kWaveLds;
+    uint2 *cands = static_cast<uint2 *>(fs.cands);
     switch (variant) {
-    case 1: k_fused_f32s<true, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
-    case 2: k_fused_f32s<false, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
-    case 3: k_fused_f32s<false, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
-    default: k_fused_f32s<true, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, peaks, dbg); break;
+    case 1: k_fused_f32s<true, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
+    case 2: k_fused_f32s<false, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
+    case 3: k_fused_f32s<false, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
+    default: k_fused_f32s<true, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
     }
+    if (variant == 0 || variant == 2)
+        k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
 }
 
 }  // namespace hr

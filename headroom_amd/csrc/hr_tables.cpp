@@ -160,7 +160,9 @@ static void build_tp_tiles(RateTables &rt)
                             const long u = m * step / P - 16L * p;      // position inside the tile, 0..15
                             const int ph = static_cast<int>(m * step % P);
                             const int tap = kappa - 1 - static_cast<int>(u);  // output uses frames pos-15 .. pos+16
-                            if (tap >= 0 && tap < kSwrTaps) v = rt.swr_taps[static_cast<size_t>(ph) * kSwrTaps + tap];
+                            // phase 0 is a unit impulse (the output IS the input sample): the kernel takes those
+                            // outputs exactly from the sample peak, so their rows stay zero and are never candidates
+                            if (ph != 0 && tap >= 0 && tap < kSwrTaps) v = rt.swr_taps[static_cast<size_t>(ph) * kSwrTaps + tap];
                         }
                         rt.tp_atab[((((static_cast<size_t>(p) * MT + mt) * 3 + ks) * 64) + lane) * 8 + i] =
                             f32_to_f16_rn(static_cast<float>(v));

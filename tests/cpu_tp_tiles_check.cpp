@@ -91,6 +91,10 @@ int main(int argc, char **argv)
             const long u = m * step / P;
             const int ph = static_cast<int>(m * step % P);
             if (u < 16L * t || u >= 16L * t + 16) { std::printf("tile %d row %d: position %ld outside tile\n", t, row, u); return 1; }
+            if (ph == 0) {  // pass-through outputs are not screened (taken exactly from the sample peak)
+                if (approx != 0) { std::printf("tile %d row %d: phase-0 row is not zero\n", t, row); return 1; }
+                continue;
+            }
             double exact = 0;
             for (int i = 0; i < 32; i++) exact = std::fma(static_cast<double>(X(u - 15 + i)), rt->swr_taps[static_cast<size_t>(ph) * 32 + i], exact);
             worst = std::fmax(worst, std::fabs(exact - approx));
