@@ -85,6 +85,10 @@ struct hr_ctx {
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // the bounds-checked generic kernels that finish the tracks of the fused kernel (last hop, ragged tail) are
+    // latency-bound and tiny: they run beside the fused kernel on a second stream
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float last_total_ms = 0, last_main_ms = 0;
 
     size_t comb_off = 0, comb_n = 0;  // combine work items of the last run_measure
@@ -130,8 +134,9 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     rd.swr_step = rt->swr_step;
     rd.swr_l1 = rt->swr_l1;
     void *g = nullptr;
-    HIPCHK(hipMalloc(&g, rt->g.size() * sizeof(double)));
+    HIPCHK(hipMalloc(&g, rt->g.size() * sizeof(double) + 2048));  // the fused kernel's 1 KiB slices read past the end
     ctx->rate_allocs.push_back(g);
+    HIPCHK(hipMemset(g, 0, rt->g.size() * sizeof(double) + 2048));
     HIPCHK(hipMemcpy(g, rt->g.data(), rt->g.size() * sizeof(double), hipMemcpyHostToDevice));
     rd.g = static_cast<const double *>(g);
     if (rt->swr_phases > 0) {
@@ -311,6 +316,21 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
+    // fork: generic kernels on the side stream (everything they read has been issued on st before this point)
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    for (int f = 0; f < 5; f++)
+        launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), ctx->side);
+    if (do_peaks) {
+        for (int f = 0; f < 5; f++)
+            for (int kind = 0; kind < 2; kind++) {
+                if (!pk_span[f][kind].n) continue;
+                launch_true_peak_generic(f, kind == 1 ? HR_TP_SAMPLE : ctx->cfg.tp_mode, dt, dr, ctx->bs_taps.as<double>(),
+                                         di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n), kPeakSpan,
+                                         ctx->peaks.as<unsigned long long>(), ctx->side);
+            }
+    }
+    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     {
         const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
@@ -327,17 +347,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                           fs2, ctx->peaks.as<unsigned long long>(), v0 == 3 ? 3 : 1, dbg, st);
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
-    for (int f = 0; f < 5; f++)
-        launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), st);
-    if (do_peaks) {
-        for (int f = 0; f < 5; f++)
-            for (int kind = 0; kind < 2; kind++) {
-                if (!pk_span[f][kind].n) continue;
-                launch_true_peak_generic(f, kind == 1 ? HR_TP_SAMPLE : ctx->cfg.tp_mode, dt, dr, ctx->bs_taps.as<double>(),
-                                         di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n), kPeakSpan,
-                                         ctx->peaks.as<unsigned long long>(), st);
-            }
-    }
+    HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     ctx->comb_off = comb_span.off;
     ctx->comb_n = comb_span.n;
     if (do_combine)
@@ -518,6 +528,9 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     }
     for (auto &e : ctx->ev)
         if (hipEventCreate(&e) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
+    if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
     int rc = upload(ctx->ebu_energy, ebur128_bin_energy().data(), kEbuBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_energy, loudnorm_bin_energy().data(), kLnBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_bounds, loudnorm_bin_bounds().data(), (kLnBins + 1) * sizeof(double), ctx->stream);
@@ -540,6 +553,9 @@ void hr_destroy(hr_ctx *ctx)
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
     delete ctx->shard_group;
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+    if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -17,8 +17,9 @@
 //     fragments come straight from the lane's own registers (v_cvt_pkrtz + v_permlane32_swap), never
 //     from LDS.  The f16 product is only a SCREEN with a rigorous error bound err = 4.1e-3*S + 4e-7
 //     (S = sample peak seen so far): an output can be the maximum only if |approx| + err >= lb, where
-//     lb = max(S, max|approx| - err) is a proven lower bound of the true peak.  Those few candidates are
-//     appended to a per-wave list (no atomics, no waiting) and k_refine_cands re-evaluates the ones that
+//     lb = max(S, max|approx| - err) is a proven lower bound of the true peak.  Those few candidates (in
+//     groups of the 16 outputs a lane holds of one accumulator) are appended to a per-wave list (no
+//     atomics, no waiting) and k_refine_cands re-evaluates the ones that
 //     still matter against the track's final bound exactly (f64 FMA chain in the oracle's tap order), so
 //     the reported peak is the exact f64 maximum over all outputs: bit-identical to the generic kernel and
 //     to the oracle.  A wave whose list overflows flags its track, which then takes the generic kernel.
@@ -44,7 +45,7 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) double *cdouble_p;
 typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 
-constexpr int kWaveLds = 8192 + 9 * 1024;  // LDS bytes per wave
+constexpr int kWaveLds = 8192 + 9 * 1024 + 2048;  // LDS bytes per wave: pieces, coefficient tiles, 2 x carry-table slices
 constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
 
 constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
@@ -138,7 +139,19 @@ struct KState {
     double x1, x2, y1, y2, z1, z2, e0, q0, q1, q2, q3;
 };
 
-__device__ __forceinline__ void kw_sample(KState &s, const KCoef &k, float xf, cdouble_p g)
+struct G4 {
+    double g0, g1, g2, g3;
+};
+
+// one frame's four carry-table values from the wave's LDS slice (same address in every lane: a broadcast read)
+__device__ __forceinline__ G4 lds_g4(const char *p)
+{
+    const double2 a = *reinterpret_cast<const double2 *>(p);
+    const double2 b = *reinterpret_cast<const double2 *>(p + 16);
+    return G4{a.x, a.y, b.x, b.y};
+}
+
+__device__ __forceinline__ void kw_sample(KState &s, const KCoef &k, float xf, const G4 &g)
 {
     const double x0 = static_cast<double>(xf);
     double tt = k.pb0 * x0;
@@ -151,10 +164,10 @@ __device__ __forceinline__ void kw_sample(KState &s, const KCoef &k, float xf, c
     v = fma(-k.ra2, s.z2, v);
     const double z0 = fma(-k.ra1, s.z1, v);
     s.e0 = fma(z0, z0, s.e0);
-    s.q0 = fma(z0, g[0], s.q0);
-    s.q1 = fma(z0, g[1], s.q1);
-    s.q2 = fma(z0, g[2], s.q2);
-    s.q3 = fma(z0, g[3], s.q3);
+    s.q0 = fma(z0, g.g0, s.q0);
+    s.q1 = fma(z0, g.g1, s.q1);
+    s.q2 = fma(z0, g.g2, s.q2);
+    s.q3 = fma(z0, g.g3, s.q3);
     s.x2 = s.x1; s.x1 = x0;
     s.y2 = s.y1; s.y1 = y0;
     s.z2 = s.z1; s.z1 = z0;
@@ -188,7 +201,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * 8ull;
     char *lbuf = smem + wave * kWaveLds;
     char *abuf = lbuf + 8192;
-    cdouble_p g = (cdouble_p)r.g;
+    char *gbuf = abuf + 9 * 1024;  // [2][1 KiB]: carry-table slice of the current / next step
+    const char *gsrc = reinterpret_cast<const char *>(r.g) + lane * 16;  // 512 B (16 frames x 4 doubles) per step
     const int T_full = static_cast<int>(hop / 16), rem = static_cast<int>(hop % 16);
 
     // ---- DMA geometry: instruction j moves LDS slots 8j..8j+7 (one 128-byte piece each, 8 lanes per piece)
@@ -274,11 +288,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     };
     make_frags(2);  // the prologue piece is "piece -1"
 
-    // tile bookkeeping (wave-uniform): outputs m_lo .. m_lo+count-1 belong to tile t
-    const int P = r.swr_phases, step = r.swr_step;
+    // tile bookkeeping (wave-uniform): the coefficient pattern of tile t is t mod NP
     const int NP = r.tp_np, MT = r.tp_mt;
-    const int q16 = (16 * P) / step, r16 = (16 * P) % step;
-    int tq = 0, tr = 0;   // floor and remainder of 16*t*P/step for the tile being screened
     int pat = 0;
 
     // first piece
@@ -287,6 +298,10 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wave_base + dma_off[j]),
                                          (__attribute__((address_space(3))) void *)(lbuf + j * 1024), 16, 0, 0);
 
+    // carry-table slice of step 0 (1 KiB moved, the first 512 B are the step's; the table is padded)
+    if constexpr (DO_KW)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
+                                         (__attribute__((address_space(3))) void *)gbuf, 16, 0, 0);
     // coefficient tiles of tile 0
     if constexpr (DO_TP) {
         const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + lane * 16;
@@ -304,11 +319,12 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         // the last piece of a hop may be partial (44.1 kHz: 4410 = 275*16 + 10): K-weight its frames one at a
         // time straight from LDS, before the buffer is handed back to the DMA
         if (DO_KW && rem && k == T_full) {
-            cdouble_p gk = g + static_cast<size_t>(k) * 64;
+            const char *gk = gbuf + (k & 1) * 1024;
             for (int i = 0; i < rem; i++) {
                 const float2 x = *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8);
-                kw_sample(ks[0], kc, x.x, gk + i * 4);
-                kw_sample(ks[1], kc, x.y, gk + i * 4);
+                const G4 g4 = lds_g4(gk + i * 32);
+                kw_sample(ks[0], kc, x.x, g4);
+                kw_sample(ks[1], kc, x.y, g4);
             }
         }
         // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
@@ -318,6 +334,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             for (int j = 0; j < 8; j++)
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + dma_off[j]),
                                                  (__attribute__((address_space(3))) void *)(lbuf + j * 1024), 16, 0, 0);
+            if constexpr (DO_KW)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + static_cast<size_t>(k + 1) * 512),
+                                                 (__attribute__((address_space(3))) void *)(gbuf + ((k + 1) & 1) * 1024), 16, 0, 0);
         }
         // rotate the fragment history and append piece k
 #pragma unroll
@@ -331,10 +350,6 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 
         // ---- K3: screen tile k-1 (pieces k-2, k-1, k)
         if (DO_TP && k >= 1) {
-            const int m_lo = tq + (tr > 0);
-            int nq = tq + q16, nr = tr + r16;
-            if (nr >= step) { nr -= step; nq++; }
-            const int count = (nq + (nr > 0)) - m_lo;
             // error bound of this tile's approximations and candidate threshold, per channel.  S covers every
             // frame of the tile's window (it includes piece k), so err bounds |approx - exact| for all outputs
             // screened so far; lb is a proven lower bound of the true peak, so an output below lb - err cannot
@@ -343,11 +358,10 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
             for (int ch = 0; ch < 2; ch++) {
                 S[ch] = wave_max_f32(s_lane[ch]);
-                err[ch] = S[ch] < kF16Safe ? fmaf(kScreenRel, S[ch], kScreenAbs) : __builtin_inff();
+                err[ch] = fmaf(kScreenRel, S[ch], kScreenAbs);
                 lb[ch] = fmaxf(lb[ch], S[ch]);
-                thr[ch] = S[ch] < kF16Safe ? lb[ch] - err[ch] : -1.0f;
+                thr[ch] = fmaxf(lb[ch] - err[ch], 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
             }
-            unsigned flags = 0;  // bit (mt*4 + ch*2 + nt): this lane holds a candidate in that accumulator
 #pragma unroll
             for (int mt = 0; mt < 3; mt++) {
                 if (mt >= MT || (dbg & 4)) continue;
@@ -366,48 +380,22 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
                         for (int i = 0; i < 16; i += 2) m0 = fmaxf(fmaxf(fabsf(acc[i]), fabsf(acc[i + 1])), m0);
                         alb[ch] = fmaxf(alb[ch], m0);
-                        if ((m0 >= thr[ch]) && (m0 > 0.0f || thr[ch] < 0.0f)) flags |= 1u << (mt * 4 + ch * 2 + nt);
-                    }
-            }
-            if (!(dbg & 1) && __ballot(flags != 0) != 0ull) {
-                // rare: recompute the flagged accumulators and append their candidate outputs to the wave's list
-#pragma unroll 1
-                for (int mt = 0; mt < MT; mt++) {
-                    if (__ballot((flags >> (mt * 4)) & 15u) == 0ull) continue;
-                    uint4v af[3];
-#pragma unroll
-                    for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + (mt * 3 + k3) * 1024 + lane * 16);
-#pragma unroll
-                    for (int ch = 0; ch < 2; ch++)
-#pragma unroll
-                        for (int nt = 0; nt < 2; nt++) {
-                            const bool flag = (flags >> (mt * 4 + ch * 2 + nt)) & 1u;
-                            if (__ballot(flag) == 0ull) continue;
-                            floatx16 acc = {0};
-#pragma unroll
-                            for (int k3 = 0; k3 < 3; k3++)
-                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
-                            // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31)
-                            // (columns past n_rows shadow the last row: never appended)
-                            const int crow = 32 * nt + (lane & 31);
-                            const int row_base = 32 * mt + 4 * (lane >> 5);
-#pragma unroll
-                            for (int i = 0; i < 16; i++) {
-                                const float a = fabsf(acc[i]);
-                                const int rowidx = row_base + (i & 3) + 8 * (i >> 2);
-                                const bool c = flag && crow < n_rows && a >= thr[ch] && (a > 0.0f || thr[ch] < 0.0f) && rowidx < count;
-                                const unsigned long long mask = __ballot(c);
-                                if (mask == 0ull) continue;
-                                const unsigned slot = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
-                                                                                          __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0));
-                                if (c && slot < kCandCap)
-                                    my_cands[slot] = make_uint2(static_cast<unsigned>(ch) | static_cast<unsigned>(crow) << 1 |
-                                                                    static_cast<unsigned>(m_lo + rowidx) << 7,
-                                                                __float_as_uint(a));
-                                n_cand += static_cast<unsigned>(__popcll(mask));
-                            }
+                        // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31), output
+                        // rows 32*mt + 4*(lane>>5) + {0..3} + 8*{0..3} of tile k-1.  If any of them can still be the
+                        // maximum, the whole group goes on the wave's list (columns past n_rows only shadow the last row).
+                        const bool flag = m0 >= thr[ch] && (32 * nt + (lane & 31)) < n_rows;
+                        const unsigned long long mask = __ballot(flag);
+                        if (mask != 0ull && !(dbg & 1)) {  // wave-uniform, rare
+                            const unsigned slot = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                                                      __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0));
+                            if (flag && slot < kCandCap)
+                                my_cands[slot] = make_uint2(static_cast<unsigned>(ch) | static_cast<unsigned>(32 * nt + (lane & 31)) << 1 |
+                                                                static_cast<unsigned>(mt) << 7 | static_cast<unsigned>(lane >> 5) << 9 |
+                                                                static_cast<unsigned>(k - 1) << 10,
+                                                            __float_as_uint(m0));
+                            n_cand += static_cast<unsigned>(__popcll(mask));
                         }
-                }
+                    }
             }
             // new proven lower bounds for the next tile
 #pragma unroll
@@ -416,8 +404,6 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 const float A = wave_max_f32(alb[ch]);
                 lb[ch] = fmaxf(lb[ch], A - err[ch]);
             }
-            tq = nq;
-            tr = nr;
             pat = pat + 1 == NP ? 0 : pat + 1;
         }
 
@@ -432,13 +418,14 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 
         // ---- K1/K2a: K-weight the 16 frames of piece k
         if (DO_KW && k < T_full) {
-            cdouble_p gk = g + static_cast<size_t>(k) * 64;
+            const char *gk = gbuf + (k & 1) * 1024;
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                kw_sample(ks[0], kc, v[c].x, gk + (2 * c) * 4);
-                kw_sample(ks[1], kc, v[c].y, gk + (2 * c) * 4);
-                kw_sample(ks[0], kc, v[c].z, gk + (2 * c + 1) * 4);
-                kw_sample(ks[1], kc, v[c].w, gk + (2 * c + 1) * 4);
+                const G4 ga = lds_g4(gk + (2 * c) * 32), gb = lds_g4(gk + (2 * c + 1) * 32);
+                kw_sample(ks[0], kc, v[c].x, ga);
+                kw_sample(ks[1], kc, v[c].y, ga);
+                kw_sample(ks[0], kc, v[c].z, gb);
+                kw_sample(ks[1], kc, v[c].w, gb);
             }
         }
     }
@@ -490,14 +477,28 @@ __global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__re
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
     const uint2 e = cands[static_cast<size_t>(blockIdx.x) * kCandCap + threadIdx.x];
-    const int ch = e.x & 1u, crow = (e.x >> 1) & 63u, m = static_cast<int>(e.x >> 7);
+    const int ch = e.x & 1u, crow = (e.x >> 1) & 63u, mt = (e.x >> 7) & 3u, half = (e.x >> 9) & 1u;
+    const int tile = static_cast<int>(e.x >> 10);
     const float lbf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 0]);
     const float Sf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 1]);
-    const float err = fmaf(kScreenRel, Sf, kScreenAbs);  // >= the bound that held when the candidate was screened
+    const float err = fmaf(kScreenRel, Sf, kScreenAbs);  // >= the bound that held when the group was screened
     if (__uint_as_float(e.y) + err < lbf) return;        // cannot reach the track's proven lower bound
-    const double a = exact_output(t, r.swr_taps, r.swr_phases, r.swr_step, static_cast<int64_t>(it.first_hop + crow) * t.hop, ch, m);
-    if (a > 0.0)
-        atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + ch], static_cast<unsigned long long>(__double_as_longlong(a)));
+    const int P = r.swr_phases, step = r.swr_step;
+    const long num0 = 16L * tile * P, num1 = 16L * (tile + 1) * P;
+    const int m_lo = static_cast<int>((num0 + step - 1) / step);
+    const int count = static_cast<int>((num1 + step - 1) / step) - m_lo;
+    const int64_t row_frame0 = static_cast<int64_t>(it.first_hop + crow) * t.hop;
+    double best = 0.0;
+    for (int i = 0; i < 16; i++) {
+        const int rowidx = 32 * mt + 4 * half + (i & 3) + 8 * (i >> 2);
+        if (rowidx >= count) continue;
+        const int m = m_lo + rowidx;
+        if ((m * step) % P == 0) continue;  // pass-through phase: taken exactly from the sample peak
+        const double a = exact_output(t, r.swr_taps, P, step, row_frame0, ch, m);
+        best = a > best ? a : best;
+    }
+    if (best > 0.0)
+        atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + ch], static_cast<unsigned long long>(__double_as_longlong(best)));
 }
 
 size_t fused_cand_bytes(uint32_t n_items) { return static_cast<size_t>(n_items) * kCandCap * sizeof(uint2); }
