@@ -243,6 +243,17 @@ class Meter:
         _check(lib().hr_shard_head(self._h, C.byref(spec.c), head.ctypes.data_as(C.POINTER(C.c_double))), "hr_shard_head")
         return head
 
+    def shard_tail(self, spec):
+        """The last 16 frames of a shard as doubles (hr_shard_head on an offset view): what the right
+        neighbour needs as left_tail before anybody has run pass 1."""
+        t = spec.c
+        assert t.frames >= 16
+        off = (t.frames - 16) * t.channels * _FMT_BYTES[t.fmt]
+        view = TrackSpec.__new__(TrackSpec)
+        view.keep, view.channels = spec.keep, spec.channels
+        view.c = HrTrack((t.pcm or 0) + off, 16, t.sample_rate, t.channels, t.fmt, t.ch_weight, t.flags, 0)
+        return self.shard_head(view)
+
     def shard_pass1(self, spec, left_tail, right_head):
         edge = HrShardEdge()
         lp = left_tail.ctypes.data_as(C.POINTER(C.c_double)) if left_tail is not None else None

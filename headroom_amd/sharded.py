@@ -1,0 +1,145 @@
+"""Multi-GPU drivers over the C ABI: one process per GPU, `torch.distributed` for the exchange steps.
+
+Two ways the path shards:
+
+* track batches -- independent units, no data-path collective: `partition_tracks` gives every rank its
+  slice, `gather_results` puts the per-rank results back in input order (what analyze_files' par_iter
+  does across threads, src/cli.rs:403-435);
+* one long stream cut in time -- `cut_stream` picks hop-aligned cuts, `analyze_stream_shard` runs
+  hr_shard_head / pass1 / pass2 / finish with a neighbour exchange of `hr_shard_edge` and an all-reduce
+  of `hr_shard_partial` in between.
+
+The backend is whatever the process group was created with: "nccl" (RCCL over xGMI) on the GPUs,
+"gloo" in the CPU tests.  Payloads are a few KB; both steps are latency-bound.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import HrShardEdge, HrShardPartial, MAX_CH
+
+MIN_SHARD_HOPS = 6  # hr_shard_pass1: a shard hands the records of its last 6 hops to the right
+
+
+def partition_tracks(n_tracks, world, rank):
+    """Contiguous, balanced slice [lo, hi) of the track list for `rank` (sizes differ by at most one)."""
+    base, extra = divmod(n_tracks, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def cut_stream(frames, sample_rate, world):
+    """Frame offsets [c_0 = 0, ..., c_world = frames] of `world` time shards: every cut is a multiple of
+    the hop, every shard but the last holds at least MIN_SHARD_HOPS whole hops.  Ranks that would get
+    less are given empty shards (c_i == c_{i+1}) at the END of the list and sit the passes out."""
+    hop = sample_rate // 10
+    n_hops = frames // hop
+    active = max(1, min(world, n_hops // MIN_SHARD_HOPS))
+    cuts = [0]
+    for r in range(1, active):
+        cuts.append((n_hops * r // active) * hop)
+    cuts.append(frames)
+    cuts += [frames] * (world - active)
+    return cuts
+
+
+def active_shards(cuts):
+    """Number of non-empty shards of a cut list from `cut_stream` (they come first)."""
+    return sum(1 for a, b in zip(cuts[:-1], cuts[1:]) if b > a)
+
+
+def _comm_device(dist):
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _as_bytes(struct):
+    return np.frombuffer(memoryview(struct).cast("B"), dtype=np.uint8)
+
+
+def exchange_edges(dist, edge, rank, active):
+    """Neighbour exchange among ranks 0..active-1: every rank sends its hr_shard_edge to rank+1.
+    Returns the left neighbour's edge (None on rank 0)."""
+    import torch
+    dev = _comm_device(dist)
+    ops, left_buf = [], None
+    if rank + 1 < active:
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(_as_bytes(edge).copy()).to(dev), rank + 1))
+    if rank > 0:
+        left_buf = torch.empty(C.sizeof(HrShardEdge), dtype=torch.uint8, device=dev)
+        ops.append(dist.P2POp(dist.irecv, left_buf, rank - 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    return None if left_buf is None else HrShardEdge.from_buffer_copy(left_buf.cpu().numpy().tobytes())
+
+
+def allreduce_partial(dist, partial):
+    """All-reduce of hr_shard_partial: counts and the kept-power sum add, the peaks take the maximum."""
+    import torch
+    dev = _comm_device(dist)
+    counts = np.empty(8001 + 2, dtype=np.int64)
+    counts[:8001] = np.ctypeslib.as_array(partial.hist).astype(np.int64)
+    counts[8001], counts[8002] = partial.n_kept, partial.n_blocks
+    tc = torch.from_numpy(counts).to(dev)
+    ts = torch.tensor([partial.sum_kept], dtype=torch.float64, device=dev)
+    tp = torch.from_numpy(np.ctypeslib.as_array(partial.peak_per_ch).copy()).to(dev)
+    dist.all_reduce(tc, op=dist.ReduceOp.SUM)
+    dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+    dist.all_reduce(tp, op=dist.ReduceOp.MAX)
+    out = HrShardPartial()
+    c = tc.cpu().numpy()
+    np.ctypeslib.as_array(out.hist)[:] = c[:8001].astype(np.uint64)
+    out.n_kept, out.n_blocks = int(c[8001]), int(c[8002])
+    out.sum_kept = float(ts.cpu()[0])
+    np.ctypeslib.as_array(out.peak_per_ch)[:] = tp.cpu().numpy()
+    return out
+
+
+def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels):
+    """One rank's part of a time-sharded stream.  `shard_spec` is this rank's TrackSpec (None for a rank
+    with an empty shard).  Every rank of the group must call this; all get the same result dict."""
+    part = HrShardPartial()
+    if shard_spec is not None and rank < active:
+        head = meter.shard_head(shard_spec)
+        # pass 1 needs the neighbours' 16-frame halos: tails travel right, heads travel left
+        left_tail, right_head = _exchange_halos(dist, meter, shard_spec, head, rank, active)
+        edge = meter.shard_pass1(shard_spec, left_tail, right_head)
+        left_edge = exchange_edges(dist, edge, rank, active)
+        part = meter.shard_pass2(left_edge)
+    red = allreduce_partial(dist, part)
+    return meter.shard_finish(red, channels)
+
+
+def _exchange_halos(dist, meter, shard_spec, head, rank, active):
+    """left_tail (the 16 frames before the shard) and right_head (the 16 after) for pass 1."""
+    import torch
+    dev = _comm_device(dist)
+    tail = meter.shard_tail(shard_spec)
+    ops, lt, rh = [], None, None
+    if rank + 1 < active:
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(tail.reshape(-1).copy()).to(dev), rank + 1))
+        rh = torch.empty(16 * MAX_CH, dtype=torch.float64, device=dev)
+        ops.append(dist.P2POp(dist.irecv, rh, rank + 1))
+    if rank > 0:
+        ops.append(dist.P2POp(dist.isend, torch.from_numpy(head.reshape(-1).copy()).to(dev), rank - 1))
+        lt = torch.empty(16 * MAX_CH, dtype=torch.float64, device=dev)
+        ops.append(dist.P2POp(dist.irecv, lt, rank - 1))
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+    lt = None if lt is None else lt.cpu().numpy().reshape(16, MAX_CH).copy()
+    rh = None if rh is None else rh.cpu().numpy().reshape(16, MAX_CH).copy()
+    return lt, rh
+
+
+def gather_results(dist, local_results, n_tracks, world):
+    """Per-rank result lists -> one list in input order on every rank (tiny: a few doubles per track)."""
+    gathered = [None] * world
+    dist.all_gather_object(gathered, local_results)
+    out = []
+    for r in range(world):
+        lo, hi = partition_tracks(n_tracks, world, r)
+        assert len(gathered[r]) == hi - lo
+        out.extend(gathered[r])
+    return out

@@ -1,0 +1,172 @@
+"""Worker for the multi-process tests (launched by torch.distributed.run, world size >= 2, backend gloo).
+
+mode "cpu": the N>1 host logic of headroom_amd.sharded without a GPU -- track partition / result gather,
+            neighbour exchange and all-reduce on ctypes structs, and the data flow of a time-sharded
+            stream with a recording stand-in for the meter.
+mode "gpu": the same drivers over the real C ABI, every rank with its own context on cuda:0, checked
+            against the unsharded result and the oracle.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import headroom_amd as hr  # noqa: E402
+from headroom_amd import sharded  # noqa: E402
+
+
+class RecordingMeter:
+    """Stand-in with the Meter's shard interface: computes nothing, records what the driver hands it."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        self.seen = {}
+
+    def _frames(self, spec, sl):
+        out = np.zeros((16, hr.MAX_CH))
+        out[:, :spec.pcm.shape[1]] = spec.pcm[sl]
+        return out
+
+    def shard_head(self, spec):
+        return self._frames(spec, slice(0, 16))
+
+    def shard_tail(self, spec):
+        return self._frames(spec, slice(-16, None))
+
+    def shard_pass1(self, spec, left_tail, right_head):
+        self.seen["left_tail"], self.seen["right_head"] = left_tail, right_head
+        e = hr.HrShardEdge()
+        e.n_hops = spec.pcm.shape[0] // 4800
+        np.ctypeslib.as_array(e.rec)[:] = 1000.0 * self.rank + np.arange(6 * 8 * 9).reshape(6, 8, 9)
+        np.ctypeslib.as_array(e.tail)[:] = self.shard_tail(spec)
+        return e
+
+    def shard_pass2(self, left_edge):
+        self.seen["left_edge"] = left_edge
+        p = hr.HrShardPartial()
+        p.hist[self.rank] = 1 + self.rank
+        p.hist[8000] = 7
+        p.sum_kept = 0.5 + self.rank
+        p.n_kept = 10 + self.rank
+        p.n_blocks = 100 + self.rank
+        p.peak_per_ch[0] = 0.25 * (self.rank + 1)
+        p.peak_per_ch[1] = 1.0 / (self.rank + 1)
+        return p
+
+    def shard_finish(self, red, channels):
+        return red
+
+
+class FakeSpec:
+    def __init__(self, pcm):
+        self.pcm = pcm
+
+
+def mode_cpu(rank, world):
+    # --- track batches: every track analysed exactly once, results back in input order ------------
+    for n in (0, 1, world, 7, 1000):
+        lo, hi = sharded.partition_tracks(n, world, rank)
+        mine = [("track", i) for i in range(lo, hi)]
+        allr = sharded.gather_results(dist, mine, n, world)
+        assert allr == [("track", i) for i in range(n)], (n, allr[:4])
+        sizes = [b - a for a, b in (sharded.partition_tracks(n, world, r) for r in range(world))]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+
+    # --- stream cuts ------------------------------------------------------------------------------
+    fs = 48000
+    frames = 4800 * 61 + 1000
+    cuts = sharded.cut_stream(frames, fs, world)
+    assert cuts[0] == 0 and cuts[-1] == frames and len(cuts) == world + 1
+    for a, b in zip(cuts[:-2], cuts[1:-1]):
+        assert (b - a) % 4800 == 0 and (b - a) // 4800 >= sharded.MIN_SHARD_HOPS
+    short = sharded.cut_stream(4800 * 7, fs, world)  # too short to split: one active shard
+    assert short == [0] + [4800 * 7] * world
+    assert sharded.cut_stream(0, fs, world) == [0] * (world + 1)
+
+    # --- data flow of a time-sharded stream -------------------------------------------------------
+    rng = np.random.default_rng(5)
+    pcm = rng.standard_normal((frames, 2))
+    m = RecordingMeter(rank)
+    spec = FakeSpec(pcm[cuts[rank]:cuts[rank + 1]])
+    red = sharded.analyze_stream_shard(dist, m, spec, rank, world, 2)
+    if rank > 0:
+        assert np.array_equal(m.seen["left_tail"][:, :2], pcm[cuts[rank] - 16:cuts[rank]])
+        le = m.seen["left_edge"]
+        assert le.n_hops == (cuts[rank] - cuts[rank - 1]) // 4800
+        assert np.ctypeslib.as_array(le.rec)[5, 7, 8] == 1000.0 * (rank - 1) + 431
+        assert np.array_equal(np.ctypeslib.as_array(le.tail)[:, :2], pcm[cuts[rank] - 16:cuts[rank]])
+    else:
+        assert m.seen["left_tail"] is None and m.seen["left_edge"] is None
+    if rank + 1 < world:
+        assert np.array_equal(m.seen["right_head"][:, :2], pcm[cuts[rank + 1]:cuts[rank + 1] + 16])
+    else:
+        assert m.seen["right_head"] is None
+    # the all-reduce: counts and the power sum add, peaks take the maximum; identical on every rank
+    for r in range(world):
+        assert red.hist[r] == 1 + r
+    assert red.hist[8000] == 7 * world and red.hist[world] == 0
+    assert red.sum_kept == sum(0.5 + r for r in range(world))
+    assert red.n_kept == sum(10 + r for r in range(world)) and red.n_blocks == sum(100 + r for r in range(world))
+    assert red.peak_per_ch[0] == 0.25 * world and red.peak_per_ch[1] == 1.0 and red.peak_per_ch[2] == 0.0
+
+    # --- a rank with an empty shard sits the passes out but joins the reduction --------------------
+    m2 = RecordingMeter(rank)
+    red2 = sharded.analyze_stream_shard(dist, m2, FakeSpec(pcm[:4800 * 7]) if rank == 0 else None, rank, 1, 2)
+    assert red2.n_blocks == 100 and red2.hist[0] == 1 and (rank == 0) == bool(m2.seen)
+
+
+def mode_gpu(rank, world):
+    import signals
+    from oracle_lib import Oracle
+    torch.cuda.set_device(0)
+    oracle = Oracle()
+    fs = 48000
+    pcm = signals.seeded_noise(91, 4800 * 83 + 777, 2, -19.0)
+    pcm[: fs * 2] *= 0.003
+    with hr.Meter(device=0) as m:
+        # one long stream, cut in time
+        cuts = sharded.cut_stream(pcm.shape[0], fs, world)
+        spec = hr.TrackSpec(pcm[cuts[rank]:cuts[rank + 1]].copy(), fs)
+        got = sharded.analyze_stream_shard(dist, m, spec, rank, world, 2)
+        whole = m.analyze(pcm, fs)
+        ref = oracle.measure(pcm, fs)
+        assert got["n_blocks"] == whole["n_blocks"] == ref["n_blocks"], (got, whole)
+        assert got["n_gated"] == whole["n_gated"]
+        assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
+        assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+        assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+        # the same with the shard resident in HBM (device pointers, offset view for the tail)
+        dev = torch.from_numpy(pcm[cuts[rank]:cuts[rank + 1]].copy()).cuda()
+        got_d = sharded.analyze_stream_shard(dist, m, hr.TrackSpec(dev, fs), rank, world, 2)
+        assert got_d == got
+        # a batch of independent tracks, split over the ranks
+        tracks = [signals.seeded_noise(200 + i, fs * 3 + 100 * i, 2, -12.0 - i) for i in range(5)]
+        lo, hi = sharded.partition_tracks(len(tracks), world, rank)
+        mine = m.analyze_batch([hr.TrackSpec(t, fs) for t in tracks[lo:hi]])
+        allr = sharded.gather_results(dist, mine, len(tracks), world)
+        single = m.analyze_batch([hr.TrackSpec(t, fs) for t in tracks])
+        assert allr == single
+
+
+def main():
+    mode = sys.argv[1]
+    dist.init_process_group(backend="gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    try:
+        {"cpu": mode_cpu, "gpu": mode_gpu}[mode](rank, world)
+        dist.barrier()
+        if rank == 0:
+            print(f"dist_worker {mode}: ok (world {world})")
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
