@@ -11,7 +11,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libheadroom_hip.so")
+# HEADROOM_HIP_LIB: another build of the same library (experiments, packaging)
+LIB_PATH = os.environ.get("HEADROOM_HIP_LIB") or os.path.join(_HERE, "libheadroom_hip.so")
 
 MAX_CH = 8
 FMT_F32, FMT_S16, FMT_S24, FMT_S32, FMT_F64 = range(5)

@@ -82,6 +82,7 @@ struct hr_ctx {
     std::vector<FusedItem> h_fitems;
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<WorkItem> h_ovf_items;
+    bool serial_tail = false;  // HR_SERIAL_TAIL=1 (timing experiments): tail kernels before the fused kernel, not beside it
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -133,6 +134,8 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     rd.swr_phases = rt->swr_phases;
     rd.swr_step = rt->swr_step;
     rd.swr_l1 = rt->swr_l1;
+    rd.q_n0 = rt->q_n0;
+    std::memcpy(rd.q_ab, rt->q_ab, sizeof rd.q_ab);
     void *g = nullptr;
     HIPCHK(hipMalloc(&g, rt->g.size() * sizeof(double) + 2048));  // the fused kernel's 1 KiB slices read past the end
     ctx->rate_allocs.push_back(g);
@@ -154,6 +157,7 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
             rd.tp_atab = at;
             rd.tp_np = rt->tp_np;
             rd.tp_mt = rt->tp_mt;
+            rd.tp_last_rows = rt->tp_max_out - 32 * (rt->tp_mt - 1);
         }
     }
     ctx->rate_fs.push_back(fs);
@@ -241,16 +245,34 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
-    size_t fused_split = 0;  // [0, split): K-weight + true peak, [split, end): K-weight only
-    for (int pass = 0; pass < 2; pass++) {
-        for (size_t i = 0; i < nt; i++) {
-            if (!fkw[i] || (ftp[i] != 0) != (pass == 0)) continue;
-            const uint64_t interior = g.descs[i].n_hops - 1;
-            for (uint64_t h = 0; h < interior; h += 64)
-                fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
+    // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
+    // class 6 = K-weight only
+    constexpr int kFusedClasses = 7;
+    size_t class_off[kFusedClasses + 1];
+    // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
+    // mixes rates: every (class, rate) run is padded to a multiple of 4 with n_rows == 0 copies of its last item.
+    for (int cls = 0; cls < kFusedClasses; cls++) {
+        class_off[cls] = fitems.size();
+        for (size_t ri = 0; ri < ctx->rates_h.size(); ri++) {
+            const size_t run_begin = fitems.size();
+            for (size_t i = 0; i < nt; i++) {
+                if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri)) continue;
+                const RateDev &rd = ctx->rates_h[ri];
+                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) : kFusedClasses - 1;
+                if (mine != cls) continue;
+                const uint64_t interior = g.descs[i].n_hops - 1;
+                for (uint64_t h = 0; h < interior; h += 64)
+                    fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
+            }
+            if (fitems.size() > run_begin)
+                while ((fitems.size() - run_begin) % 4) {
+                    FusedItem pad = fitems.back();
+                    pad.n_rows = 0;
+                    fitems.push_back(pad);
+                }
         }
-        if (pass == 0) fused_split = fitems.size();
     }
+    class_off[kFusedClasses] = fitems.size();
     if (!fitems.empty()) {
         rc = upload(ctx->fitems_d, fitems.data(), fitems.size() * sizeof(FusedItem), st);
         if (rc) return rc;
@@ -317,34 +339,36 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
     // fork: generic kernels on the side stream (everything they read has been issued on st before this point)
+    hipStream_t tail_st = ctx->serial_tail ? st : ctx->side;
     HIPCHK(hipEventRecord(ctx->ev_fork, st));
-    HIPCHK(hipStreamWaitEvent(ctx->side, ctx->ev_fork, 0));
+    if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
     for (int f = 0; f < 5; f++)
-        launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), ctx->side);
+        launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), tail_st);
     if (do_peaks) {
         for (int f = 0; f < 5; f++)
             for (int kind = 0; kind < 2; kind++) {
                 if (!pk_span[f][kind].n) continue;
                 launch_true_peak_generic(f, kind == 1 ? HR_TP_SAMPLE : ctx->cfg.tp_mode, dt, dr, ctx->bs_taps.as<double>(),
                                          di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n), kPeakSpan,
-                                         ctx->peaks.as<unsigned long long>(), ctx->side);
+                                         ctx->peaks.as<unsigned long long>(), tail_st);
             }
     }
-    HIPCHK(hipEventRecord(ctx->ev_join, ctx->side));
+    HIPCHK(hipEventRecord(ctx->ev_join, tail_st));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
     {
         const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
         // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
         const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
-        launch_fused_f32s(dt, dr, fi, static_cast<uint32_t>(fused_split), ctx->recs.as<HopRec>(), fs,
-                          ctx->peaks.as<unsigned long long>(), v0, dbg, st);
-        FusedScratch fs2 = fs;
-        if (fs2.cands) {
-            fs2.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(fused_split));
-            fs2.cand_cnt = fs.cand_cnt + fused_split;
+        for (int cls = 0; cls < kFusedClasses; cls++) {
+            const size_t off = class_off[cls], n = class_off[cls + 1] - off;
+            if (!n) continue;
+            FusedScratch fsc = fs;
+            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
+            fsc.cand_cnt = fs.cand_cnt + off;
+            const bool tp = cls < kFusedClasses - 1;
+            launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
+                              ctx->peaks.as<unsigned long long>(), tp ? v0 : (v0 == 3 ? 3 : 1), cls, dbg, st);
         }
-        launch_fused_f32s(dt, dr, fi + fused_split, static_cast<uint32_t>(fitems.size() - fused_split), ctx->recs.as<HopRec>(),
-                          fs2, ctx->peaks.as<unsigned long long>(), v0 == 3 ? 3 : 1, dbg, st);
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
@@ -521,6 +545,7 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     ctx->cfg = c;
     if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
     if (const char *ab = std::getenv("HR_ABLATE")) ctx->ablate = std::atoi(ab);
+    if (const char *se = std::getenv("HR_SERIAL_TAIL")) ctx->serial_tail = std::atoi(se) != 0;
     if (c.stream) ctx->stream = static_cast<hipStream_t>(c.stream);
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HR_ERR_HIP; }

@@ -22,6 +22,9 @@ struct RateDev {
     const double *swr_taps;  // [(phases+1)][32] f64
     const void *tp_atab;     // f16 A fragments of the MFMA screen, [tp_np][tp_mt][3][64][8 halfs]; nullptr: no fused path
     int32_t tp_np, tp_mt;
+    int32_t tp_last_rows;    // outputs in the last 32-row block of the largest tile (max outputs - 32*(tp_mt-1))
+    uint32_t q_n0;           // RateTables::q_n0 / q_ab: where q[0], q[1] start riding on q[2], q[3]
+    double q_ab[2][2];
     uint32_t hop;
     int32_t swr_phases, swr_step;
     double swr_l1;

@@ -31,8 +31,11 @@ struct FusedScratch {
     unsigned *overflow;  // [n_tracks]: a wave's list overflowed -> the track's peak must be redone generically, zeroed per call
 };
 size_t fused_cand_bytes(uint32_t n_items);
+// All items of one launch share a true-peak class (the kernel is specialised on the tile shape of the rate).
+int fused_tp_class(int tp_mt, int tp_last_rows);
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
-                       HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int dbg, hipStream_t st);
+                       HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int tp_class, int dbg,
+                       hipStream_t st);
 
 // hr_synth.hip
 struct SynthPar {

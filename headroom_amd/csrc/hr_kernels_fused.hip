@@ -31,6 +31,8 @@
 // src/analyzer.rs:253-267); SURVEY.md Appendix A.2 / A.4.
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "hr_device.hpp"
 #include "hr_kernels.hpp"
 
@@ -45,7 +47,12 @@ typedef unsigned uint4v __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) double *cdouble_p;
 typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 
-constexpr int kWaveLds = 8192 + 9 * 1024 + 2048;  // LDS bytes per wave: pieces, coefficient tiles, 2 x carry-table slices
+// LDS of one workgroup (4 waves that run the same steps of same-rate tracks in lock step):
+//   4 x 8 KiB   one PCM piece buffer per wave
+//   2 x 9 KiB   coefficient tiles of the tile being screened / the next one, shared by the four waves
+//   2 x 1 KiB   carry-table slice of this step / the next one, shared
+constexpr int kPieceLds = 8192, kCoefLds = 9 * 1024, kCarryLds = 1024;
+constexpr int kGroupLds = 4 * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
 constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
 
 constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
@@ -173,7 +180,70 @@ __device__ __forceinline__ void kw_sample(KState &s, const KCoef &k, float xf, c
     s.z2 = s.z1; s.z1 = z0;
 }
 
-template <bool DO_KW, bool DO_TP>
+// the same without q[0], q[1]: past RateDev::q_n0 they are rebuilt from q[2], q[3]
+__device__ __forceinline__ void kw_sample_short(KState &s, const KCoef &k, float xf, double g2, double g3)
+{
+    const double x0 = static_cast<double>(xf);
+    double tt = k.pb0 * x0;
+    tt = fma(k.pb1, s.x1, tt);
+    tt = fma(k.pb2, s.x2, tt);
+    tt = fma(-k.pa2, s.y2, tt);
+    const double y0 = fma(-k.pa1, s.y1, tt);
+    double v = fma(-2.0, s.y1, y0);
+    v = v + s.y2;
+    v = fma(-k.ra2, s.z2, v);
+    const double z0 = fma(-k.ra1, s.z1, v);
+    s.e0 = fma(z0, z0, s.e0);
+    s.q2 = fma(z0, g2, s.q2);
+    s.q3 = fma(z0, g3, s.q3);
+    s.x2 = s.x1; s.x1 = x0;
+    s.y2 = s.y1; s.y1 = y0;
+    s.z2 = s.z1; s.z1 = z0;
+}
+
+// LDS-DMA of 16 bytes per lane: global (uniform base + 32-bit lane offset) -> LDS (uniform base + lane*16).
+// The offset passes through an empty asm so that its zero-extension stays next to the add and the
+// instruction is selected in its scalar-base form (no 64-bit vector address arithmetic per DMA).
+__device__ __forceinline__ void dma16(const char *base, unsigned lane_off, char *lds)
+{
+    asm volatile("" : "+v"(lane_off));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off),
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+}
+
+// MT: 32-output blocks per tile (1..3); SMALL: the last block holds at most 8 outputs (44.1 kHz: outputs 64..69
+// of 70), so only the first four accumulator registers of its groups can be non-zero.
+// LDS reads the compiler must not see as LDS reads.  After a global_load_lds the compiler cannot tell which
+// part of LDS the DMA will write, so it puts s_waitcnt vmcnt(0) in front of every later ds_read -- here that
+// would stall each step on the PCM piece it has just requested.  The buffers these helpers read (coefficient
+// tiles, carry-table slices) were requested one step earlier and are covered by the step's opening
+// s_waitcnt vmcnt(0).  The asm hides the access; lds_wait() is the matching lgkmcnt wait and ties the
+// registers to it so that no use is scheduled in front of it; its memory clobber keeps a later DMA into the
+// buffer just read from being moved in front of the reads.
+__device__ __forceinline__ unsigned lds_addr(const void *p)
+{
+    return static_cast<unsigned>(reinterpret_cast<size_t>((const __attribute__((address_space(3))) char *)p));
+}
+__device__ __forceinline__ uint4v lds_ld128(unsigned addr, int off)
+{
+    uint4v r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "i"(off));
+    return r;
+}
+__device__ __forceinline__ void lds_wait(uint4v &a, uint4v &b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b) : : "memory"); }
+__device__ __forceinline__ void lds_wait(uint4v &a, uint4v &b, uint4v &c) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c) : : "memory"); }
+__device__ __forceinline__ void lds_wait(uint4v &a, uint4v &b, uint4v &c, uint4v &d)
+{
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : : "memory");
+}
+__device__ __forceinline__ double2 as_double2(uint4v u)
+{
+    union { uint4v u; double2 d; } c;
+    c.u = u;
+    return c.d;
+}
+
+template <bool DO_KW, bool DO_TP, int MT, bool SMALL>
 __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restrict__ tracks,
                                                        const RateDev *__restrict__ rates,
                                                        const FusedItem *__restrict__ items, uint32_t n_items,
@@ -182,28 +252,33 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                                                        unsigned *__restrict__ overflow,
                                                        unsigned long long *__restrict__ peaks, int dbg)
 {
-    // dbg (timing experiments only, results are wrong when set): 1 = never refine, 2 = no coefficient DMA,
-    // 4 = no MFMA screen, 8 = no bound updates
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // 4 waves x (8 KiB pieces + 9 KiB coefficient tiles)
+    // dbg (timing experiments only, results are wrong when set): 1 = never list candidates,
+    // 16 = no PCM / carry-table DMA after the first piece
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // kGroupLds
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t item_idx = blockIdx.x * 4 + wave;
-    if (item_idx >= n_items) return;  // whole wave leaves; no workgroup barrier is used in this kernel
+    // (the host pads every rate's item list to a multiple of 4 with n_rows == 0 items: the four waves of a
+    // workgroup share tables and a barrier per step, so all of them run all steps)
     const FusedItem it = items[item_idx];
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
     const KCoef kc = r.k;
     const uint32_t hop = t.hop;
     const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
-    const int n_rows = static_cast<int>(it.n_rows);
-    const int row = lane < n_rows ? lane : n_rows - 1;  // idle lanes shadow the last row
+    const int n_rows = static_cast<int>(it.n_rows);  // 0: a padding item (computes on row 0, reports nothing)
+    const int last_row = n_rows > 0 ? n_rows - 1 : 0;
+    const int row = lane < n_rows ? lane : last_row;  // idle lanes shadow the last row
     const uint64_t h = it.first_hop + row;
     const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * 8ull;
-    char *lbuf = smem + wave * kWaveLds;
-    char *abuf = lbuf + 8192;
-    char *gbuf = abuf + 9 * 1024;  // [2][1 KiB]: carry-table slice of the current / next step
-    const char *gsrc = reinterpret_cast<const char *>(r.g) + lane * 16;  // 512 B (16 frames x 4 doubles) per step
+    char *lbuf = smem + wave * kPieceLds;
+    char *abuf = smem + 4 * kPieceLds;    // [2][9 KiB]: step k reads half k&1
+    char *gbuf = abuf + 2 * kCoefLds;     // [2][1 KiB]: step k reads half k&1
+    const char *gsrc = reinterpret_cast<const char *>(r.g);  // 512 B (16 frames x 4 doubles) per step
+    const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
     const int T_full = static_cast<int>(hop / 16), rem = static_cast<int>(hop % 16);
+    // steps >= k_short accumulate only q[2], q[3] (RateDev::q_n0)
+    const int k_short = r.q_n0 < hop ? static_cast<int>(r.q_n0 / 16) : T + 1;
 
     // ---- DMA geometry: instruction j moves LDS slots 8j..8j+7 (one 128-byte piece each, 8 lanes per piece)
     unsigned dma_off[8];
@@ -211,11 +286,17 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     for (int j = 0; j < 8; j++) {
         const int slot = 8 * j + (lane >> 3);
         const int chunk = (lane & 7) ^ ((slot >> 1) & 7);
-        const int srow = slot < n_rows ? slot : n_rows - 1;
+        const int srow = slot < n_rows ? slot : last_row;
         dma_off[j] = static_cast<unsigned>(srow) * hop * 8u + static_cast<unsigned>(chunk) * 16u;
     }
     const unsigned rd_swz = (lane >> 1) & 7;
     const char *my_lds = lbuf + lane * 128;
+
+    // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
+    if constexpr (DO_TP) {
+#pragma unroll
+        for (int i = 0; i < 3 * MT; i++) *reinterpret_cast<uint4v *>(abuf + i * 1024 + lane * 16) = uint4v{0, 0, 0, 0};  // (all four waves write the same zeros)
+    }
 
     // ---- prologue: the 16 frames in front of the row (FIR window of tile 0, filter input history)
     float4 v[8];
@@ -247,7 +328,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         }
     }
 
-    // signal fragments of the three newest pieces: [age][channel][n-tile]
+    // Signal fragments of the three newest pieces: [slot][channel][n-tile]; piece p lives in slot p mod 3.
+    // Nothing is ever moved between slots: the coefficient chunk that belongs to a slot's piece is put
+    // where that slot expects it when the tile's coefficients are DMA'd into LDS (scalar address math).
     uint4v hist[3][2][2];
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -259,11 +342,21 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     // per channel: the peak is reported per channel, so every bound is per channel too
     float s_lane[2] = {0.0f, 0.0f};  // max |x| this lane has seen (exact)
     float alb[2] = {0.0f, 0.0f};     // max |approx output| this lane has seen
-    float lb[2] = {0.0f, 0.0f};      // wave-uniform proven lower bound of the channel's true peak
+    // wave-uniform, refreshed only when a lane outgrows them (rare after the first steps):
+    float S_u[2] = {-1.0f, -1.0f};   // wave maximum of s_lane at the last refresh
+    float A_u[2] = {0.0f, 0.0f};     // wave maximum of alb at the last refresh
+    float lb[2] = {0.0f, 0.0f};      // proven lower bound of the channel's true peak
+    float thr_l[2][2];               // [ch][n-tile] candidate threshold of this lane's column; +inf past n_rows
+#pragma unroll
+    for (int c = 0; c < 2; c++) thr_l[c][0] = thr_l[c][1] = __builtin_inff();
     unsigned n_cand = 0;             // wave-uniform: candidates appended so far
     uint2 *__restrict__ my_cands = cands + static_cast<size_t>(item_idx) * kCandCap;
 
-    auto make_frags = [&](int age) {
+    auto make_frags = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+#ifdef HR_EXP_NO_FRAGS
+        if constexpr (DO_TP) { hist[slot][0][0][0] ^= __float_as_uint(v[0].x); return; }
+#endif
         if constexpr (DO_TP) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -281,158 +374,325 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     const auto sw = __builtin_amdgcn_permlane32_swap(f[ch][j], f[ch][j + 4], false, false);
-                    hist[age][ch][0][j] = sw[0];
-                    hist[age][ch][1][j] = sw[1];
+                    hist[slot][ch][0][j] = sw[0];
+                    hist[slot][ch][1][j] = sw[1];
                 }
         }
     };
-    make_frags(2);  // the prologue piece is "piece -1"
+    make_frags(std::integral_constant<int, 2>{});  // the prologue piece is "piece -1"
 
     // tile bookkeeping (wave-uniform): the coefficient pattern of tile t is t mod NP
-    const int NP = r.tp_np, MT = r.tp_mt;
-    int pat = 0;
+    const int NP = r.tp_np;
+    int pat = 0;  // pattern of the next tile whose coefficients are fetched
+
+    // coefficient chunk ks of the tile screened at step k+1 pairs with piece k-1+ks, slot (k+2+ks) mod 3
+    // This wave's share (chunks i with i mod 4 == wave) of the coefficients of the tile that step k+1 screens,
+    // into the half of the coefficient area that step k does not read.
+    auto issue_coeff = [&](int pattern, int k, int kmod3) {
+        const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + static_cast<size_t>(pattern) * MT * 3 * 1024;
+        char *dst = abuf + ((k + 1) & 1) * kCoefLds;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int ksx = 0; ksx < 3; ksx++)
+                if (((mt * 3 + ksx) & 3) == wave)
+                    dma16(asrc + (mt * 3 + ksx) * 1024, lane16, dst + (mt * 3 + (kmod3 + 2 + ksx) % 3) * 1024);
+    };
 
     // first piece
 #pragma unroll
-    for (int j = 0; j < 8; j++)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(wave_base + dma_off[j]),
-                                         (__attribute__((address_space(3))) void *)(lbuf + j * 1024), 16, 0, 0);
-
+    for (int j = 0; j < 8; j++) dma16(wave_base, dma_off[j], lbuf + j * 1024);
     // carry-table slice of step 0 (1 KiB moved, the first 512 B are the step's; the table is padded)
-    if constexpr (DO_KW)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)gsrc,
-                                         (__attribute__((address_space(3))) void *)gbuf, 16, 0, 0);
-    // coefficient tiles of tile 0
-    if constexpr (DO_TP) {
-        const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + lane * 16;
-        for (int i = 0; i < 3 * MT; i++)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + i * 1024),
-                                             (__attribute__((address_space(3))) void *)(abuf + i * 1024), 16, 0, 0);
+    if constexpr (DO_KW) {
+        if (wave == 0) dma16(gsrc, lane16, gbuf);
     }
 
-    for (int k = 0; k <= T; k++) {
+    // One step of the row loop.  SHORT: the step accumulates only q[2], q[3] (k >= k_short); the loop is split in
+    // two so that each half has one K-weighting code path and the filter state stays put in its registers.
+    auto step = [&](int k, auto short_c, auto slot_c) {
+        constexpr bool SHORT = decltype(short_c)::value;
+        constexpr int KK = decltype(slot_c)::value;  // k mod 3
         // ---- piece k has landed?  (everything this wave has in flight: the DMA and the A fragments)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        // every wave's share of the shared tables has landed, and nobody still reads the halves that this
+        // step's DMA is about to overwrite
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
         for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(my_lds + ((c ^ rd_swz) * 16));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // the last piece of a hop may be partial (44.1 kHz: 4410 = 275*16 + 10): K-weight its frames one at a
         // time straight from LDS, before the buffer is handed back to the DMA
         if (DO_KW && rem && k == T_full) {
-            const char *gk = gbuf + (k & 1) * 1024;
+            const char *gk = gbuf + (k & 1) * kCarryLds;
             for (int i = 0; i < rem; i++) {
                 const float2 x = *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8);
-                const G4 g4 = lds_g4(gk + i * 32);
-                kw_sample(ks[0], kc, x.x, g4);
-                kw_sample(ks[1], kc, x.y, g4);
+                if constexpr (!SHORT) {
+                    const G4 g4 = lds_g4(gk + i * 32);
+                    kw_sample(ks[0], kc, x.x, g4);
+                    kw_sample(ks[1], kc, x.y, g4);
+                } else {
+                    const double2 g = *reinterpret_cast<const double2 *>(gk + i * 32 + 16);
+                    kw_sample_short(ks[0], kc, x.x, g.x, g.y);
+                    kw_sample_short(ks[1], kc, x.y, g.x, g.y);
+                }
             }
         }
         // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
-        if (k < T) {
-            const char *src = wave_base + static_cast<size_t>(k + 1) * 128;
+        if (k < T && !(dbg & 16)) {
+            const char *src = wave_base + ((dbg & 32) ? 0 : static_cast<size_t>(k + 1) * 128);  // dbg 32: re-read piece 0 (cache hits)
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + dma_off[j]),
-                                                 (__attribute__((address_space(3))) void *)(lbuf + j * 1024), 16, 0, 0);
-            if constexpr (DO_KW)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + static_cast<size_t>(k + 1) * 512),
-                                                 (__attribute__((address_space(3))) void *)(gbuf + ((k + 1) & 1) * 1024), 16, 0, 0);
+            for (int j = 0; j < 8; j++) dma16(src, dma_off[j], lbuf + j * 1024);
+            if constexpr (DO_KW) {
+                if (wave == 0) dma16(gsrc + static_cast<size_t>(k + 1) * 512, lane16, gbuf + ((k + 1) & 1) * kCarryLds);
+            }
+            if constexpr (DO_TP) {
+                issue_coeff(pat, k, KK);
+                pat = pat + 1 == NP ? 0 : pat + 1;
+            }
         }
-        // rotate the fragment history and append piece k
-#pragma unroll
-        for (int c = 0; c < 2; c++)
-#pragma unroll
-            for (int n = 0; n < 2; n++) {
-                hist[0][c][n] = hist[1][c][n];
-                hist[1][c][n] = hist[2][c][n];
-            }
-        make_frags(2);
+        // fragments of piece k go into slot k mod 3
+        make_frags(slot_c);
 
-        // ---- K3: screen tile k-1 (pieces k-2, k-1, k)
-        if (DO_TP && k >= 1) {
-            // error bound of this tile's approximations and candidate threshold, per channel.  S covers every
-            // frame of the tile's window (it includes piece k), so err bounds |approx - exact| for all outputs
-            // screened so far; lb is a proven lower bound of the true peak, so an output below lb - err cannot
-            // be the maximum.  S itself is a valid lb: phase 0 of the bank passes the samples through.
-            float S[2], err[2], thr[2];
+        if constexpr (DO_TP) {
+            // Bounds, per channel.  S_u >= every |x| of the window (it includes piece k) so err bounds
+            // |approx - exact| of everything screened so far; lb is a proven lower bound of the true peak
+            // (S itself is one: phase 0 of the bank passes the samples through), so an output below lb - err
+            // cannot be the maximum.  The wave-wide values are recomputed only when some lane has outgrown them.
+            // (one compare: a VALU compare that feeds a scalar branch costs as much as half a dozen f32 operations)
+            const float over = fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1]));
+            const bool stale = over > 0.0f;
+            if (__ballot(stale) != 0ull) {
 #pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                S[ch] = wave_max_f32(s_lane[ch]);
-                err[ch] = fmaf(kScreenRel, S[ch], kScreenAbs);
-                lb[ch] = fmaxf(lb[ch], S[ch]);
-                thr[ch] = fmaxf(lb[ch] - err[ch], 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
+                for (int ch = 0; ch < 2; ch++) {
+                    S_u[ch] = wave_max_f32(s_lane[ch]);
+                    A_u[ch] = wave_max_f32(alb[ch]);
+                    const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
+                    lb[ch] = fmaxf(lb[ch], fmaxf(S_u[ch], A_u[ch] - err));
+                    const float thr = fmaxf(lb[ch] - err, 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
+                    thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
+                    thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
+                }
             }
+        }
+
+        // ---- the hot block, branch-free so that the scheduler can run the f64 K-weighting of piece k under
+        // the MFMAs of tile k-1 (pieces k-2, k-1, k): K3 screen ...
+        float m0[MT][2][2];
+        auto screen = [&]() {
+            if constexpr (DO_TP) {
 #pragma unroll
-            for (int mt = 0; mt < 3; mt++) {
-                if (mt >= MT || (dbg & 4)) continue;
-                uint4v af[3];
+                for (int mt = 0; mt < MT; mt++) {
+                    uint4v af[3];
 #pragma unroll
-                for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + (mt * 3 + k3) * 1024 + lane * 16);
+                    for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + (k & 1) * kCoefLds + (mt * 3 + k3) * 1024 + lane * 16);
 #pragma unroll
-                for (int ch = 0; ch < 2; ch++)
+                    for (int ch = 0; ch < 2; ch++) {
 #pragma unroll
-                    for (int nt = 0; nt < 2; nt++) {
-                        floatx16 acc = {0};
+                        for (int nt = 0; nt < 2; nt++) {
+                            floatx16 acc = {0};
 #pragma unroll
-                        for (int k3 = 0; k3 < 3; k3++)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
-                        float m0 = 0.0f;
+                            for (int k3 = 0; k3 < 3; k3++)
+                                acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
+                            // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31),
+                            // output rows 32*mt + 4*(lane>>5) + {0..3} + 8*{0..3} of the tile
+                            float m = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+                            if (!(SMALL && mt == MT - 1)) {
 #pragma unroll
-                        for (int i = 0; i < 16; i += 2) m0 = fmaxf(fmaxf(fabsf(acc[i]), fabsf(acc[i + 1])), m0);
-                        alb[ch] = fmaxf(alb[ch], m0);
-                        // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31), output
-                        // rows 32*mt + 4*(lane>>5) + {0..3} + 8*{0..3} of tile k-1.  If any of them can still be the
-                        // maximum, the whole group goes on the wave's list (columns past n_rows only shadow the last row).
-                        const bool flag = m0 >= thr[ch] && (32 * nt + (lane & 31)) < n_rows;
-                        const unsigned long long mask = __ballot(flag);
-                        if (mask != 0ull && !(dbg & 1)) {  // wave-uniform, rare
+                                for (int i = 4; i < 16; i += 2) m = fmaxf(fmaxf(fabsf(acc[i]), fabsf(acc[i + 1])), m);
+                            }
+                            m0[mt][ch][nt] = m;
+                        }
+                        alb[ch] = fmaxf(fmaxf(m0[mt][ch][0], m0[mt][ch][1]), alb[ch]);
+                    }
+                }
+            }
+        };
+        // Both at once, software-pipelined by hand: each accumulator's three MFMAs are issued, then a slice of the
+        // f64 K-weighting (which does not depend on them) keeps the VALU busy while the matrix pipe works, then
+        // the accumulator is reduced.  The fences pin that order; the carry-table values of the next slice are
+        // fetched one slice ahead.  (Without DO_TP this is just the K-weighting in eight slices.)
+        auto fused_block = [&]() {
+            const unsigned g_at = lds_addr(gbuf) + static_cast<unsigned>(k & 1) * kCarryLds;  // wave-uniform: broadcast reads
+            const unsigned a_at = lds_addr(abuf) + static_cast<unsigned>(k & 1) * kCoefLds + lane16;
+            struct GC { uint4v r[4]; };  // rows 2c, 2c+1 of the slice: {g0 g1}, {g2 g3} each (SHORT: only {g2 g3})
+            auto load_gc = [&](int c) {
+                GC o;
+                if constexpr (!SHORT) {
+                    o.r[0] = lds_ld128(g_at, (2 * c) * 32);
+                    o.r[1] = lds_ld128(g_at, (2 * c) * 32 + 16);
+                    o.r[2] = lds_ld128(g_at, (2 * c + 1) * 32);
+                    o.r[3] = lds_ld128(g_at, (2 * c + 1) * 32 + 16);
+                } else {
+                    o.r[1] = lds_ld128(g_at, (2 * c) * 32 + 16);
+                    o.r[3] = lds_ld128(g_at, (2 * c + 1) * 32 + 16);
+                    o.r[0] = o.r[2] = uint4v{0, 0, 0, 0};
+                }
+                return o;
+            };
+            auto wait_gc = [&](GC &g) {
+                if constexpr (!SHORT) lds_wait(g.r[0], g.r[1], g.r[2], g.r[3]);
+                else lds_wait(g.r[1], g.r[3]);
+            };
+            // sample i of slice c: i = 0, 1 are the two channels of frame 2c, i = 2, 3 of frame 2c+1
+            auto ksample = [&](int c, int i, const GC &g) {
+                const float x = i == 0 ? v[c].x : i == 1 ? v[c].y : i == 2 ? v[c].z : v[c].w;
+                const double2 g23 = as_double2(g.r[i < 2 ? 1 : 3]);
+                if constexpr (!SHORT) {
+                    const double2 g01 = as_double2(g.r[i < 2 ? 0 : 2]);
+                    kw_sample(ks[i & 1], kc, x, G4{g01.x, g01.y, g23.x, g23.y});
+                } else {
+                    kw_sample_short(ks[i & 1], kc, x, g23.x, g23.y);
+                }
+            };
+            constexpr int NG = DO_TP ? 4 * MT : 8;     // accumulator groups of the tile
+            constexpr int CPG = NG >= 8 ? 1 : 8 / NG;  // K slices (of 2 frames x 2 channels) per group
+            uint4v af[3];
+            if constexpr (DO_TP) {
+#pragma unroll
+                for (int k3 = 0; k3 < 3; k3++) af[k3] = lds_ld128(a_at, k3 * 1024);
+            }
+            GC gcur = load_gc(0);
+            if constexpr (DO_TP) lds_wait(af[0], af[1], af[2]);
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const int mt = g >> 2, ch = (g >> 1) & 1, nt = g & 1;
+                // MFMA 1, sample, MFMA 2 (needs 1's result: the sample in between covers its latency), sample,
+                // MFMA 3, the slice's other samples
+                floatx16 acc = {0};
+                const int c0 = g * CPG;
+                if (c0 < 8) wait_gc(gcur);
+                GC gnext = gcur;
+                if (c0 + 1 < 8) gnext = load_gc(c0 + 1);
+#pragma unroll
+                for (int k3 = 0; k3 < 3; k3++) {
+                    if constexpr (DO_TP) {
+#ifndef HR_EXP_NO_MFMA
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
+#else
+                        acc[k3] += __uint_as_float(af[k3][0] ^ hist[k3][ch][nt][0]);
+#endif
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#ifndef HR_EXP_NO_KW
+                    if (c0 < 8) {
+                        ksample(c0, k3, gcur);
+                        if (k3 == 2) ksample(c0, 3, gcur);
+                    }
+#endif
+                    if constexpr (DO_TP) __builtin_amdgcn_sched_barrier(0);
+                }
+                gcur = gnext;
+#pragma unroll
+                for (int j = 1; j < CPG; j++) {
+                    const int c = c0 + j;
+                    if (c < 8) {
+                        wait_gc(gcur);
+                        gnext = gcur;
+                        if (c + 1 < 8) gnext = load_gc(c + 1);
+#pragma unroll
+                        for (int i = 0; i < 4; i++) ksample(c, i, gcur);
+                        gcur = gnext;
+                    }
+                }
+                if constexpr (DO_TP) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    // all sixteen accumulator registers stay reserved until the MFMAs have retired
+                    asm volatile("" : "+v"(acc));
+                    // this lane's 16 values are column (lane&31) of n-tile nt, i.e. wave row 32*nt + (lane&31),
+                    // output rows 32*mt + 4*(lane>>5) + {0..3} + 8*{0..3} of the tile
+                    float m = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+#ifndef HR_EXP_NO_REDUCE
+                    if (!(SMALL && mt == MT - 1)) {
+#pragma unroll
+                        for (int i = 4; i < 16; i += 2) m = fmaxf(fmaxf(fabsf(acc[i]), fabsf(acc[i + 1])), m);
+                    }
+#endif
+                    m0[mt][ch][nt] = m;
+                    if (nt == 1) alb[ch] = fmaxf(fmaxf(m0[mt][ch][0], m0[mt][ch][1]), alb[ch]);
+#ifndef HR_EXP_NO_AF
+                    if ((g & 3) == 3 && mt + 1 < MT) {  // the block's MFMAs are done: fetch the next block's fragments
+#pragma unroll
+                        for (int k3 = 0; k3 < 3; k3++) af[k3] = lds_ld128(a_at, ((mt + 1) * 3 + k3) * 1024);
+                        lds_wait(af[0], af[1], af[2]);
+                    }
+#endif
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        const bool fused_step = DO_KW && k < T_full;
+        if (fused_step) {
+            fused_block();
+        } else {
+            screen();
+        }
+        if constexpr (DO_TP) {
+            // groups that can still hold the maximum go on the wave's list (columns past n_rows have an infinite
+            // threshold; step 0 screens zeros against an infinite threshold)
+            float margin = -__builtin_inff();  // max over the lane's groups of (group maximum - its threshold)
+#pragma unroll
+            for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                for (int nt = 0; nt < 2; nt++) {
+                    float mm = m0[0][ch][nt];
+#pragma unroll
+                    for (int mt = 1; mt < MT; mt++) mm = fmaxf(mm, m0[mt][ch][nt]);
+                    margin = fmaxf(margin, mm - thr_l[ch][nt]);
+                }
+            const unsigned long long any = __ballot(margin >= 0.0f);
+            if (any != 0ull && !(dbg & 1)) {  // wave-uniform, rare
+#pragma unroll
+                for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                        for (int nt = 0; nt < 2; nt++) {
+                            const bool flag = m0[mt][ch][nt] >= thr_l[ch][nt];
+                            const unsigned long long mask = __ballot(flag);
+                            if (mask == 0ull) continue;
                             const unsigned slot = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
                                                                                       __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0));
                             if (flag && slot < kCandCap)
                                 my_cands[slot] = make_uint2(static_cast<unsigned>(ch) | static_cast<unsigned>(32 * nt + (lane & 31)) << 1 |
                                                                 static_cast<unsigned>(mt) << 7 | static_cast<unsigned>(lane >> 5) << 9 |
                                                                 static_cast<unsigned>(k - 1) << 10,
-                                                            __float_as_uint(m0));
+                                                            __float_as_uint(m0[mt][ch][nt]));
                             n_cand += static_cast<unsigned>(__popcll(mask));
                         }
-                    }
             }
-            // new proven lower bounds for the next tile
-#pragma unroll
-            for (int ch = 0; ch < 2; ch++) {
-                if (dbg & 8) continue;
-                const float A = wave_max_f32(alb[ch]);
-                lb[ch] = fmaxf(lb[ch], A - err[ch]);
-            }
-            pat = pat + 1 == NP ? 0 : pat + 1;
         }
+    };
 
-        // ---- the next tile's coefficient tiles (this tile's LDS reads are done)
-        if (DO_TP && k < T && !(dbg & 2)) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + static_cast<size_t>(pat) * MT * 3 * 1024 + lane * 16;
-            for (int i = 0; i < 3 * MT; i++)
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(asrc + i * 1024),
-                                                 (__attribute__((address_space(3))) void *)(abuf + i * 1024), 16, 0, 0);
+    // The loop runs in triples so that k mod 3 (the fragment slot of piece k) is a compile-time constant;
+    // both phases start at a multiple of 3 (q_n0 is a multiple of 48 frames).
+    auto run = [&](int k_begin, int k_end, auto short_c) {
+        for (int k = k_begin; k < k_end; k += 3) {
+            step(k, short_c, std::integral_constant<int, 0>{});
+            if (k + 1 < k_end) step(k + 1, short_c, std::integral_constant<int, 1>{});
+            if (k + 2 < k_end) step(k + 2, short_c, std::integral_constant<int, 2>{});
         }
-
-        // ---- K1/K2a: K-weight the 16 frames of piece k
-        if (DO_KW && k < T_full) {
-            const char *gk = gbuf + (k & 1) * 1024;
+    };
+    {
+        const int k_split = k_short < T + 1 ? k_short : T + 1;
+        run(0, k_split, std::false_type{});
+        if (DO_KW && k_split <= T) {
+            // from here on q[0], q[1] ride on q[2], q[3]: g_j = ab[j][0] g_2 + ab[j][1] g_3 for the rest of the hop
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                const G4 ga = lds_g4(gk + (2 * c) * 32), gb = lds_g4(gk + (2 * c + 1) * 32);
-                kw_sample(ks[0], kc, v[c].x, ga);
-                kw_sample(ks[1], kc, v[c].y, ga);
-                kw_sample(ks[0], kc, v[c].z, gb);
-                kw_sample(ks[1], kc, v[c].w, gb);
+            for (int c = 0; c < 2; c++) {
+                ks[c].q0 -= fma(r.q_ab[0][0], ks[c].q2, r.q_ab[0][1] * ks[c].q3);
+                ks[c].q1 -= fma(r.q_ab[1][0], ks[c].q2, r.q_ab[1][1] * ks[c].q3);
             }
         }
+        run(k_split, T + 1, std::true_type{});
     }
 
     if (DO_KW && lane < n_rows) {
 #pragma unroll
         for (int c = 0; c < 2; c++) {
+            if (k_short <= T) {
+                ks[c].q0 += fma(r.q_ab[0][0], ks[c].q2, r.q_ab[0][1] * ks[c].q3);
+                ks[c].q1 += fma(r.q_ab[1][0], ks[c].q2, r.q_ab[1][1] * ks[c].q3);
+            }
             HopRec &o = recs[t.rec_base + (kPreRec + h) * 2 + c];
             o.e0 = ks[c].e0;
             o.q[0] = ks[c].q0; o.q[1] = ks[c].q1; o.q[2] = ks[c].q2; o.q[3] = ks[c].q3;
@@ -441,16 +701,20 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     }
     if constexpr (DO_TP) {
         // hand the wave's list and bounds over to k_refine_cands (next kernel on the stream)
-        float Sf[2];
+        float Sf[2], Af[2];
 #pragma unroll
-        for (int c = 0; c < 2; c++) Sf[c] = wave_max_f32(s_lane[c]);
+        for (int c = 0; c < 2; c++) {
+            Sf[c] = wave_max_f32(s_lane[c]);
+            Af[c] = wave_max_f32(alb[c]);
+            lb[c] = fmaxf(lb[c], fmaxf(Sf[c], Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
+        }
         if (lane == 0) {
             cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
             if (n_cand > kCandCap || Sf[0] >= kF16Safe || Sf[1] >= kF16Safe) overflow[it.track] = 1u;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 // non-negative floats order like their bit patterns
-                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(fmaxf(lb[c], Sf[c])));
+                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(lb[c]));
                 atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(Sf[c]));
                 // phase-0 outputs are the samples themselves: exact, and not part of the screen
                 if (Sf[c] > 0.0f)
@@ -503,18 +767,46 @@ __global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__re
 
 size_t fused_cand_bytes(uint32_t n_items) { return static_cast<size_t>(n_items) * kCandCap * sizeof(uint2); }
 
+template <bool DO_KW, bool DO_TP>
+static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStream_t st, const TrackDesc *tracks,
+                         const RateDev *rates, const FusedItem *items, uint32_t n_items, HopRec *recs, uint2 *cands,
+                         const FusedScratch &fs, unsigned long long *peaks, int dbg)
+{
+#define HR_FUSED_CASE(MT, SMALL)                                                                                      \
+    k_fused_f32s<DO_KW, DO_TP, MT, SMALL><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands,     \
+                                                                     fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg)
+    if constexpr (!DO_TP) {
+        HR_FUSED_CASE(1, false);
+    } else {
+        switch (tp_class) {
+        case 0: HR_FUSED_CASE(1, false); break;
+        case 1: HR_FUSED_CASE(1, true); break;
+        case 2: HR_FUSED_CASE(2, false); break;
+        case 3: HR_FUSED_CASE(2, true); break;
+        case 4: HR_FUSED_CASE(3, false); break;
+        default: HR_FUSED_CASE(3, true); break;
+        }
+    }
+#undef HR_FUSED_CASE
+}
+
+int fused_tp_class(int tp_mt, int tp_last_rows) { return (tp_mt - 1) * 2 + (tp_last_rows <= 8 ? 1 : 0); }
+
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
-                       HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int dbg, hipStream_t st)
+                       HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int tp_class, int dbg,
+                       hipStream_t st)
 {
     if (!n_items) return;
     const dim3 grid((n_items + 3) / 4), block(256);
-    const size_t lds = 4 * kWaveLds;
+    // (the data-movement-only ablation build takes just its piece buffers: more workgroups per CU, which shows how
+    // the stream rate depends on the bytes in flight)
+    const size_t lds = variant == 3 ? 4 * kPieceLds : kGroupLds;
     uint2 *cands = static_cast<uint2 *>(fs.cands);
     switch (variant) {
-    case 1: k_fused_f32s<true, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
-    case 2: k_fused_f32s<false, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
-    case 3: k_fused_f32s<false, false><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
-    default: k_fused_f32s<true, true><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg); break;
+    case 1: launch_class<true, false>(0, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;
+    case 2: launch_class<false, true>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;
+    case 3: launch_class<false, false>(0, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;
+    default: launch_class<true, true>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;
     }
     if (variant == 0 || variant == 2)
         k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);

@@ -145,6 +145,7 @@ static void build_tp_tiles(RateTables &rt)
     if (MT > 3) return;  // low sample rates (many phases per input frame) stay on the generic kernel
     rt.tp_np = NP;
     rt.tp_mt = MT;
+    rt.tp_max_out = static_cast<int>(max_out);
     rt.tp_atab.assign(static_cast<size_t>(NP) * MT * 3 * 64 * 8, 0);
     for (int p = 0; p < NP; p++) {
         const long m_lo = (16L * p * P + step - 1) / step;
@@ -220,6 +221,41 @@ static void build_carry(RateTables &rt)
     long double r = 0;
     for (int i = 0; i < 16; i++) r = std::fmax(r, std::fabs(Mp[i]));
     rt.carry_residual = static_cast<double>(r);
+
+    // q truncation point: fit g_j (j = 0, 1) on [n0, L) by the two RLB free modes g_2, g_3 (2x2 normal
+    // equations in long double) and take the first multiple of 48 (three 16-frame steps of the fused kernel) where the mismatch is below 1e-15.
+    rt.q_n0 = L;
+    long double norm_j[2] = {0, 0};
+    for (uint32_t n = 0; n < L; n++)
+        for (int j = 0; j < 2; j++) norm_j[j] += gl[static_cast<size_t>(n) * 4 + j] * gl[static_cast<size_t>(n) * 4 + j];
+    for (uint32_t n0 = 48; n0 + 64 <= L; n0 += 48) {
+        long double a22 = 0, a23 = 0, a33 = 0, b2[2] = {0, 0}, b3[2] = {0, 0};
+        for (uint32_t n = n0; n < L; n++) {
+            const long double *gn = &gl[static_cast<size_t>(n) * 4];
+            a22 += gn[2] * gn[2]; a23 += gn[2] * gn[3]; a33 += gn[3] * gn[3];
+            for (int j = 0; j < 2; j++) { b2[j] += gn[2] * gn[j]; b3[j] += gn[3] * gn[j]; }
+        }
+        const long double det = a22 * a33 - a23 * a23;
+        if (det == 0) break;
+        long double ab[2][2], worst = 0;
+        for (int j = 0; j < 2; j++) {
+            ab[j][0] = (b2[j] * a33 - b3[j] * a23) / det;
+            ab[j][1] = (b3[j] * a22 - b2[j] * a23) / det;
+            long double res = 0;
+            for (uint32_t n = n0; n < L; n++) {
+                const long double *gn = &gl[static_cast<size_t>(n) * 4];
+                const long double d = gn[j] - ab[j][0] * gn[2] - ab[j][1] * gn[3];
+                res += d * d;
+            }
+            worst = std::fmax(worst, std::sqrt(res / norm_j[j]));
+        }
+        if (worst < 1e-15L) {
+            rt.q_n0 = n0;
+            for (int j = 0; j < 2; j++) { rt.q_ab[j][0] = static_cast<double>(ab[j][0]); rt.q_ab[j][1] = static_cast<double>(ab[j][1]); }
+            rt.q_residual = static_cast<double>(worst);
+            break;
+        }
+    }
 }
 
 const RateTables *rate_tables(uint32_t fs)

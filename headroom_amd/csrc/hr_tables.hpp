@@ -30,6 +30,14 @@ struct RateTables {
     double G[16];            // sum_n g[n][j]*g[n][k]
     double M[kCarryTerms - 1][16];  // M^1, M^2 (row-major): state transfer over one hop
     double carry_residual = 0;      // |M^kCarryTerms|_max, must be negligible
+    // Once the pre-filter's own transient has died (n >= q_n0, a multiple of 48), the responses to the two
+    // pre-filter state components are free modes of the RLB stage, i.e. combinations of g[.][2], g[.][3]:
+    //   g[n][j] = q_ab[j][0]*g[n][2] + q_ab[j][1]*g[n][3]   (j = 0, 1; n >= q_n0)
+    // so a kernel may stop accumulating q[0], q[1] there and rebuild them from q[2], q[3].
+    // q_n0 == hop: no truncation.  q_residual: l2 norm of the mismatch over n >= q_n0 relative to |g[.][j]|.
+    uint32_t q_n0 = 0;
+    double q_ab[2][2] = {{0, 0}, {0, 0}};
+    double q_residual = 0;
     // libswresample bank to 192 kHz (phase_count == 0: no resampling, true peak = sample peak)
     int swr_phases = 0, swr_step = 0;
     std::vector<double> swr_taps;  // [(phases+1)][32]
@@ -40,6 +48,7 @@ struct RateTables {
     // the A fragments of v_mfma_f32_32x32x16_f16 (lane l: row 32*mt + (l&31), k = 16*ks + 8*(l>>5) + i).
     std::vector<uint16_t> tp_atab;
     int tp_np = 0, tp_mt = 0;
+    int tp_max_out = 0;  // most outputs any tile has
 };
 
 // Builds (and caches per process) the tables of one rate.  Returns nullptr for fs < 10.

@@ -124,9 +124,11 @@ def mode_cpu(rank, world):
 
 def mode_gpu(rank, world):
     import signals
-    from oracle_lib import Oracle
+    import oracle_lib as oracle
     torch.cuda.set_device(0)
-    oracle = Oracle()
+    if rank == 0:
+        oracle.build()
+    dist.barrier()
     fs = 48000
     pcm = signals.seeded_noise(91, 4800 * 83 + 777, 2, -19.0)
     pcm[: fs * 2] *= 0.003
