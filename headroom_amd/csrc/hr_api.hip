@@ -45,6 +45,7 @@ struct DevBuf {
 };
 
 constexpr uint32_t kPeakSpan = 8192;  // positions per workgroup of the generic true-peak kernels
+constexpr uint32_t kTailSpan = 512;   // ... for the tail of a track whose body runs on the fused kernel
 
 size_t fmt_bytes(int fmt)
 {
@@ -287,11 +288,19 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         hop_span[f].off = items.size();
         for (size_t i = 0; i < nt; i++) {
             if (g.fmts[i] != f) continue;
-            for (uint64_t h = fkw[i] ? g.descs[i].n_hops - 1 : 0; h < g.descs[i].n_hops; h += 256)
+            if (fkw[i]) continue;  // fused tracks: only the last hop is left, see tail_span
+            for (uint64_t h = 0; h < g.descs[i].n_hops; h += 256)
                 items.push_back({static_cast<uint32_t>(i), 0, h});
         }
         hop_span[f].n = items.size() - hop_span[f].off;
     }
+    // last hop of the fused tracks (all f32): one lane per (track, channel)
+    Span tail_span;
+    tail_span.off = items.size();
+    for (size_t i = 0; i < nt; i++)
+        if (fkw[i])
+            for (uint32_t c = 0; c < g.descs[i].ch; c++) items.push_back({static_cast<uint32_t>(i), c, g.descs[i].n_hops - 1});
+    tail_span.n = items.size() - tail_span.off;
     comb_span.off = items.size();
     for (size_t i = 0; i < nt; i++) {
         const auto &d = g.descs[i];
@@ -311,7 +320,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                                        (ctx->cfg.tp_mode == HR_TP_BS1770 && g.descs[i].fs >= 192000);
                     if (plain != (kind == 1)) continue;
                     const uint64_t n0 = ftp[i] ? (g.descs[i].n_hops - 1) * g.descs[i].hop : 0;
-                    for (uint64_t n = n0; n < g.descs[i].frames; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
+                    // (the tail of a fused track is cut into short items: many brief workgroups beside the fused kernel
+                    // instead of one long-running one)
+                    const uint32_t span = ftp[i] && kind == 0 && ctx->cfg.tp_mode == HR_TP_SWR192K ? kTailSpan : 0;
+                    for (uint64_t n = n0; n < g.descs[i].frames; n += span ? span : kPeakSpan)
+                        items.push_back({static_cast<uint32_t>(i), span, n});
                 }
             pk_span[f][kind].n = items.size() - pk_span[f][kind].off;
         }
@@ -344,6 +357,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
     for (int f = 0; f < 5; f++)
         launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), tail_st);
+    launch_hop_zero_state_list(HR_FMT_F32, dt, dr, di + tail_span.off, static_cast<uint32_t>(tail_span.n), ctx->recs.as<HopRec>(), tail_st);
     if (do_peaks) {
         for (int f = 0; f < 5; f++)
             for (int kind = 0; kind < 2; kind++) {

@@ -10,6 +10,9 @@ namespace hr {
 // hr_kernels_generic.hip
 void launch_hop_zero_state(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
                            uint32_t n_items, HopRec *recs, hipStream_t st);
+// one lane per item; item.first = hop, item.pad = channel
+void launch_hop_zero_state_list(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
+                                uint32_t n_items, HopRec *recs, hipStream_t st);
 void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
                         const HopRec *recs, double *hop_sums, hipStream_t st);
 void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
@@ -17,7 +20,8 @@ void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
                        const double *ln_bounds, TrackOut *outs, hipStream_t st);
-// tp_kind: 0 swr192k, 1 bs1770, 2 sample peak; every item covers `span` (multiple of 256) positions
+// tp_kind: 0 swr192k, 1 bs1770, 2 sample peak; every item covers `span` (multiple of 256) positions, or item.pad
+// positions when that is non-zero (swr192k only)
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
                               const double *bs_taps, const WorkItem *items, uint32_t n_items, uint32_t span,
                               unsigned long long *peaks, hipStream_t st);

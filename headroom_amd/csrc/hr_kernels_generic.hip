@@ -106,6 +106,58 @@ __global__ void __launch_bounds__(256) k_hop_zero_state(const TrackDesc *__restr
     }
 }
 
+// The same for a short list of single (track, hop, channel) triples, one lane each: the last hop of every track
+// that otherwise runs on the fused kernel.  (A workgroup per track would park 200 almost idle workgroups
+// beside the fused kernel for milliseconds; this takes a handful of waves.)
+template <int FMT>
+__global__ void __launch_bounds__(64) k_hop_zero_state_list(const TrackDesc *__restrict__ tracks,
+                                                            const RateDev *__restrict__ rates,
+                                                            const WorkItem *__restrict__ items, uint32_t n_items,
+                                                            HopRec *__restrict__ recs)
+{
+    const uint32_t gid = blockIdx.x * 64 + threadIdx.x;
+    if (gid >= n_items) return;
+    const WorkItem it = items[gid];
+    const TrackDesc &t = tracks[it.track];
+    const uint64_t h = it.first;
+    const int c = static_cast<int>(it.pad);
+    const RateDev &r = rates[t.rate_idx];
+    const KCoef k = r.k;
+    const int C = t.ch;
+    const uint32_t L = t.hop;
+    const int64_t n0 = static_cast<int64_t>(h) * L;
+    const double *__restrict__ g = r.g;
+    double x1 = (n0 >= 1 || t.left_tail) ? fetch<FMT>(t, c, n0 - 1, false) : 0.0;
+    double x2 = (n0 >= 2 || t.left_tail) ? fetch<FMT>(t, c, n0 - 2, false) : 0.0;
+    double y1 = 0, y2 = 0, z1 = 0, z2 = 0, e0 = 0, q0 = 0, q1 = 0, q2 = 0, q3 = 0;
+    const uint64_t base = static_cast<uint64_t>(n0) * C + c;
+#pragma unroll 8
+    for (uint32_t i = 0; i < L; i++) {
+        const double x0 = ld_sample<FMT>(t.pcm, base + static_cast<uint64_t>(i) * C);
+        double tt = k.pb0 * x0;
+        tt = fma(k.pb1, x1, tt);
+        tt = fma(k.pb2, x2, tt);
+        tt = fma(-k.pa2, y2, tt);
+        const double y0 = fma(-k.pa1, y1, tt);
+        double v = fma(-2.0, y1, y0);
+        v = v + y2;
+        v = fma(-k.ra2, z2, v);
+        const double z0 = fma(-k.ra1, z1, v);
+        e0 = fma(z0, z0, e0);
+        q0 = fma(z0, g[i * 4 + 0], q0);
+        q1 = fma(z0, g[i * 4 + 1], q1);
+        q2 = fma(z0, g[i * 4 + 2], q2);
+        q3 = fma(z0, g[i * 4 + 3], q3);
+        x2 = x1; x1 = x0;
+        y2 = y1; y1 = y0;
+        z2 = z1; z1 = z0;
+    }
+    HopRec &o = recs[t.rec_base + (kPreRec + h) * C + c];
+    o.e0 = e0;
+    o.q[0] = q0; o.q[1] = q1; o.q[2] = q2; o.q[3] = q3;
+    o.s[0] = y1; o.s[1] = y1 - y2; o.s[2] = z1; o.s[3] = z1 - z2;
+}
+
 // ---------------------------------------------------------------------------------------------
 // carry hand-off + true hop energies.  One thread per (hop, channel), hops -kPreHop .. n_hops-1.
 // ---------------------------------------------------------------------------------------------
@@ -380,6 +432,7 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
                                                        unsigned long long *__restrict__ peaks)
 {
     const WorkItem it = items[blockIdx.x];
+    if (it.pad) span = it.pad;  // a short item (the tail of a track that otherwise runs on the fused kernel)
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
     const int64_t N = static_cast<int64_t>(t.frames);
@@ -475,6 +528,13 @@ __global__ void __launch_bounds__(256) k_sample_peak(const TrackDesc *__restrict
     case 3: { constexpr int F = 3; CALL; } break; \
     default: { constexpr int F = 4; CALL; } break; \
     }
+
+void launch_hop_zero_state_list(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
+                                uint32_t n_items, HopRec *recs, hipStream_t st)
+{
+    if (!n_items) return;
+    HR_FMT_DISPATCH(fmt, (k_hop_zero_state_list<F><<<dim3((n_items + 63) / 64), dim3(64), 0, st>>>(tracks, rates, items, n_items, recs)));
+}
 
 void launch_hop_zero_state(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
                            uint32_t n_items, HopRec *recs, hipStream_t st)
