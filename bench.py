@@ -111,6 +111,14 @@ def main():
         value = hours_per_step * args.steps / elapsed
         kernel_ms = sum(main_ms) / max(len(main_ms), 1)
         achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        # HBM bytes per launch of the fused kernel: PMC counters need a profiler pass of their own, so this is the
+        # committed measurement (profiles/r1_fused_hbm_traffic.json, bytes per track) scaled to this launch
+        traffic, traffic_src = None, None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_fused_hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh)["bytes_per_track"] * n_tracks
+            traffic_src = "profiles/r1_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
         line = {
             "metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": value, "unit": "audio-hours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -120,7 +128,8 @@ def main():
                                    "(BASELINE configs[1]); per-track integrated LUFS (ebur128 gating) + dBTP (192 kHz)",
                        "tracks_per_gpu": n_tracks, "bytes_per_gpu": bytes_per_step, "parallelism": f"track-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                         "algorithmic_bytes": bytes_per_step,
                          "kernel": "K-weight + true-peak pass (HIP events on the library stream, mean over timed steps)",
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,

@@ -1,6 +1,7 @@
 // What does fetching one 128-byte piece per lane-row cost a wave that is busy with f64 arithmetic?
 //   mode 0: arithmetic only;  mode 1: 8 x global_load_lds_dwordx4 (LDS DMA) + 8 x ds_read_b128;
 //   mode 2: 8 x global_load_dwordx4 per lane straight into registers (second register set)
+//   mode 3: as mode 1 with two piece buffers per wave and the DMA two pieces ahead
 //   build: hipcc --offload-arch=gfx950 -O3 -o tools/microbench4 tools/microbench4.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -33,7 +34,16 @@ __global__ void __launch_bounds__(256, 2) k_fetch(const char *__restrict__ pcm, 
     for (int i = 0; i < 8; i++) v[i] = vn[i] = make_float4(0, 0, 0, 0);
     auto issue = [&](int k) {
         const char *src = wave_base + static_cast<size_t>(k) * 128;
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 3) {
+            char *dst = smem + wave * 16384 + (k & 1) * 8192;
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                unsigned o = dma_off[j];
+                asm volatile("" : "+v"(o));
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + o),
+                                                 (__attribute__((address_space(3))) void *)(dst + j * 1024), 16, 0, 0);
+            }
+        } else if constexpr (MODE == 1) {
 #pragma unroll
             for (int j = 0; j < 8; j++) {
                 unsigned o = dma_off[j];
@@ -49,8 +59,18 @@ __global__ void __launch_bounds__(256, 2) k_fetch(const char *__restrict__ pcm, 
         }
     };
     issue(0);
+    if constexpr (MODE == 3) issue(1);
     for (int k = 0; k < kSteps; k++) {
-        if constexpr (MODE == 1) {
+        if constexpr (MODE == 3) {
+            // piece k is the older of the two requests in flight: 8 newer DMA instructions may stay outstanding
+            if (k + 1 < kSteps) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const char *bufk = smem + wave * 16384 + (k & 1) * 8192;
+#pragma unroll
+            for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(bufk + lane * 128 + ((i ^ ((lane >> 1) & 7)) * 16));
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            if (k + 2 < kSteps) issue(k + 2);
+        } else if constexpr (MODE == 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = *reinterpret_cast<const float4 *>(lbuf + lane * 128 + ((i ^ ((lane >> 1) & 7)) * 16));
@@ -59,7 +79,7 @@ __global__ void __launch_bounds__(256, 2) k_fetch(const char *__restrict__ pcm, 
 #pragma unroll
             for (int i = 0; i < 8; i++) v[i] = vn[i];
         }
-        if (k + 1 < kSteps) issue(k + 1);
+        if (MODE != 3 && k + 1 < kSteps) issue(k + 1);
 #pragma unroll
         for (int i = 0; i < 8; i++) c[i] += v[i].x;
 #pragma unroll
@@ -76,9 +96,9 @@ static void run(const char *name, const char *pcm, double *out, int groups)
 {
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
-    k_fetch<MODE, NFMA><<<groups, 256, 32768>>>(pcm, out);
+    k_fetch<MODE, NFMA><<<groups, 256, 65536>>>(pcm, out);
     CHECK(hipEventRecord(e0));
-    k_fetch<MODE, NFMA><<<groups, 256, 32768>>>(pcm, out);
+    k_fetch<MODE, NFMA><<<groups, 256, 65536>>>(pcm, out);
     CHECK(hipEventRecord(e1));
     CHECK(hipEventSynchronize(e1));
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -99,6 +119,12 @@ int main()
     run<0, 960>("960 f64 fma, no fetch", pcm, out, groups);
     run<1, 960>("960 f64 fma + LDS DMA + ds_read", pcm, out, groups);
     run<2, 960>("960 f64 fma + per-lane loads to registers", pcm, out, groups);
+    run<3, 480>("480 f64 fma + LDS DMA two pieces ahead", pcm, out, groups);
+    run<3, 960>("960 f64 fma + LDS DMA two pieces ahead", pcm, out, groups);
+    run<3, 1200>("1200 f64 fma + LDS DMA two pieces ahead", pcm, out, groups);
+    run<1, 1200>("1200 f64 fma + LDS DMA + ds_read", pcm, out, groups);
+    run<0, 1200>("1200 f64 fma, no fetch", pcm, out, groups);
+    run<3, 0>("no arithmetic, LDS DMA two pieces ahead", pcm, out, groups);
     run<1, 0>("no arithmetic, LDS DMA + ds_read", pcm, out, groups);
     run<2, 0>("no arithmetic, per-lane loads", pcm, out, groups);
     std::printf("microbench4 exit 0\n");
