@@ -275,3 +275,44 @@ def test_full_size_track_properties(oracle, meters):
     g3 = m.analyze(swapped, fs)
     assert g3["peak_per_ch"] == got["peak_per_ch"][::-1]
     assert abs(g3["integrated_lufs"] - got["integrated_lufs"]) < 1e-9
+
+
+def test_mixed_rate_batch_on_fused_kernel(oracle, meters):
+    """One batch of stereo f32 tracks at five rates: every kernel specialisation (tile shapes 1x32, 2x32,
+    3x32 outputs, with and without the short last block) runs in the same call, every rate's run of wave
+    items is padded to whole workgroups, and lengths go from two hops to several waves of rows."""
+    m = meters()
+    cases = [(44100, 2.05), (44100, 13.7), (48000, 7.3), (48000, 0.25), (96000, 6.61), (88200, 3.3), (32000, 9.9),
+             (44100, 0.31), (96000, 0.2), (32000, 0.45)]
+    pcms = []
+    for i, (fs, secs) in enumerate(cases):
+        p = signals.seeded_noise(900 + i, int(fs * secs) + 17 * i, 2, -14.0 - i)
+        p[: len(p) // 3] *= 0.05
+        pcms.append(p)
+    got = m.analyze_batch([hr.TrackSpec(p, fs) for p, (fs, _) in zip(pcms, cases)])
+    for g, p, (fs, _) in zip(got, pcms, cases):
+        ref = oracle.measure(p, fs)
+        assert g["status"] == 0 and g["n_blocks"] == ref["n_blocks"] and g["n_gated"] == ref["n_gated"], (fs, g, ref)
+        if math.isfinite(ref["integrated_lufs"]):
+            assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6, (fs, g, ref)
+        assert g["peak_per_ch"] == ref["peak_per_ch"], (fs, g, ref)
+    # the same tracks with sample-peak metering take the K-weighting-only build of the kernel
+    ms = meters("ebur128", "sample")
+    got_s = ms.analyze_batch([hr.TrackSpec(p, fs) for p, (fs, _) in zip(pcms, cases)])
+    for g, gs in zip(got, got_s):
+        assert gs["integrated_lufs"] == g["integrated_lufs"] and gs["n_gated"] == g["n_gated"]
+
+
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_low_frequency_content_carry_terms(oracle, meters, fs):
+    """A 25 Hz tone on a DC offset makes the carry-in terms (2 s.q + s'Gs) as large as the zero-state energy:
+    the truncated carry sums of the fused kernel must still give the hop energies of the sequential filter."""
+    n = fs * 4 + 321
+    t = np.arange(n) / fs
+    pcm = np.stack([0.4 * np.sin(2 * np.pi * 25.0 * t) + 0.3, 0.2 * np.cos(2 * np.pi * 31.0 * t) - 0.25], axis=1).astype(np.float32)
+    pcm += signals.seeded_noise(5, n, 2, -60.0)
+    for engine in (0, 1):
+        H, P = meters(engine=engine).block_energies(hr.TrackSpec(pcm, fs))
+        Href = oracle.hop_sums(pcm, fs)
+        assert np.max(np.abs(H / Href - 1)) < 1e-9
+    check_against_oracle(oracle, meters(), pcm, fs)
