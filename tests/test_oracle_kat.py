@@ -198,3 +198,30 @@ def test_synth_track_is_deterministic_and_gated(oracle):
     assert r["n_gated"] < r["n_blocks"] or r["rel_threshold_lufs"] > -70
     sp = 20 * np.log10(np.max(np.abs(a)))
     assert r["true_peak_dbtp"] > sp + 0.5  # inter-sample-peak bursts
+
+
+# ---- committed golden vectors (tests/golden/make_golden.py): the oracle must keep reproducing them -------------
+
+def _golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "oracle_vectors.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.mark.parametrize("idx", range(10))
+def test_oracle_reproduces_golden_vectors(oracle, idx):
+    c = _golden()[idx]
+    pcm = oracle.synth_track(c["seed"], c["fs"], c["channels"], c["frames"])
+    assert [float(x) for x in pcm[:4].reshape(-1)] == c["pcm_head"]  # the generator itself is pinned
+    P = oracle.block_powers(oracle.hop_sums(pcm, c["fs"]), c["fs"])
+    want = np.array([float.fromhex(x) for x in c["block_powers_head"]])
+    assert np.allclose(P[:32], want, rtol=1e-12, atol=0)
+    for key, exp in c["results"].items():
+        gname, tname = key.split("/")
+        r = oracle.measure(pcm, c["fs"], gate_mode={"ebur128": 0, "exact": 1, "loudnorm": 2}[gname],
+                           tp_mode={"swr192k": 0, "bs1770": 1, "sample": 2}[tname])
+        assert r["n_blocks"] == exp["n_blocks"] and r["n_gated"] == exp["n_gated"]
+        li = float.fromhex(exp["integrated_lufs"])
+        assert r["integrated_lufs"] == li or abs(r["integrated_lufs"] - li) < 1e-10
+        assert [float.hex(float(x)) for x in r["peak_per_ch"]] == exp["peak_per_ch"]
