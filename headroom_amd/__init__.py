@@ -63,7 +63,7 @@ class HrAnalysis(C.Structure):
 
 
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
-           "hr_block_energies", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
+           "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision"]
 
 _lib = None
@@ -101,6 +101,7 @@ def lib():
                                  C.c_int, C.POINTER(HrShardEdge)]
     L.hr_shard_pass2.argtypes = [C.c_void_p, C.POINTER(HrShardEdge), C.POINTER(HrShardPartial)]
     L.hr_shard_finish.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.c_int, C.POINTER(HrResult)]
+    L.hr_analyze_stream_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(HrTrack), C.POINTER(HrResult)]
     L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hr_strerror.argtypes = [C.c_int]
@@ -273,6 +274,14 @@ class Meter:
         r = HrResult()
         _check(lib().hr_shard_finish(self._h, C.byref(partial), channels, C.byref(r)), "hr_shard_finish")
         return _result_dict(r, channels)
+
+
+def analyze_stream_sharded(meters, spec):
+    """hr_analyze_stream_sharded: one stream, time-sharded over the given Meters (one per GPU) in this process."""
+    arr = (C.c_void_p * len(meters))(*[m._h for m in meters])
+    r = HrResult()
+    _check(lib().hr_analyze_stream_sharded(arr, len(meters), C.byref(spec.c), C.byref(r)), "hr_analyze_stream_sharded")
+    return _result_dict(r, spec.channels)
 
 
 def gain_decision(input_i, input_tp, kind=KIND_LOSSLESS, bitrate_kbps=None, split=None):

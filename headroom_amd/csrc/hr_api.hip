@@ -12,6 +12,7 @@
 #include <cstring>
 #include <limits>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/headroom_hip.h"
@@ -880,6 +881,73 @@ int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_r
     std::memset(out, 0, sizeof *out);
     fill_result(ctx, o, pk, channels, out);
     return HR_OK;
+}
+
+// Config 5 inside one process: one context per GPU, the exchange steps on the host (a few KB).
+int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *track, hr_result *out)
+{
+    if (!ctxs || n_ctx < 1 || !track || !out) return HR_ERR_INVALID;
+    for (int i = 0; i < n_ctx; i++)
+        if (!ctxs[i] || ctxs[i]->cfg.gate_mode != ctxs[0]->cfg.gate_mode || ctxs[i]->cfg.tp_mode != ctxs[0]->cfg.tp_mode)
+            return HR_ERR_INVALID;
+    const int v = validate_track(ctxs[0], *track);
+    if (v) return v;
+    if (track->flags & HR_TRACK_DEVICE_PCM)  // a device pointer belongs to one GPU: all contexts must sit on it
+        for (int i = 1; i < n_ctx; i++)
+            if (ctxs[i]->cfg.device != ctxs[0]->cfg.device) return HR_ERR_INVALID;
+    const uint32_t hop = track->sample_rate / 10;
+    const uint64_t n_hops = hop ? track->frames / hop : 0;
+    const int active = static_cast<int>(std::max<uint64_t>(1, std::min<uint64_t>(n_ctx, n_hops / kPreRec)));
+    std::vector<uint64_t> cut(active + 1, 0);
+    for (int r = 1; r < active; r++) cut[r] = (n_hops * r / active) * hop;
+    cut[active] = track->frames;
+    const size_t frame_bytes = fmt_bytes(track->fmt) * track->channels;
+    std::vector<hr_track> shard(active, *track);
+    for (int r = 0; r < active; r++) {
+        shard[r].pcm = static_cast<const char *>(track->pcm) + cut[r] * frame_bytes;
+        shard[r].frames = cut[r + 1] - cut[r];
+    }
+    // halos: the 16 frames either side of every cut (host copies / small D2H reads)
+    std::vector<std::vector<double>> head(active, std::vector<double>(kHalo * HR_MAX_CH)), tail(active, std::vector<double>(kHalo * HR_MAX_CH));
+    for (int r = 0; r < active; r++) {
+        int rc = hr_shard_head(ctxs[r], &shard[r], head[r].data());
+        if (rc) return rc;
+        if (r + 1 < active) {  // every shard but the last holds at least six hops, so it has 16 frames
+            hr_track last16 = shard[r];
+            last16.pcm = static_cast<const char *>(shard[r].pcm) + (shard[r].frames - kHalo) * frame_bytes;
+            last16.frames = kHalo;
+            rc = hr_shard_head(ctxs[r], &last16, tail[r].data());
+            if (rc) return rc;
+        }
+    }
+    std::vector<hr_shard_edge> edge(active);
+    std::vector<hr_shard_partial> part(active);
+    std::vector<int> rcs(active, HR_OK);
+    auto on_all = [&](auto fn) {  // one host thread per context: the GPUs work at the same time
+        std::vector<std::thread> th;
+        for (int r = 1; r < active; r++) th.emplace_back([&, r] { rcs[r] = fn(r); });
+        rcs[0] = fn(0);
+        for (auto &t : th) t.join();
+        for (int r = 0; r < active; r++)
+            if (rcs[r]) return rcs[r];
+        return static_cast<int>(HR_OK);
+    };
+    int rc = on_all([&](int r) {
+        return hr_shard_pass1(ctxs[r], &shard[r], r ? tail[r - 1].data() : nullptr, r + 1 < active ? head[r + 1].data() : nullptr,
+                              r == 0, r + 1 == active, &edge[r]);
+    });
+    if (rc) return rc;
+    rc = on_all([&](int r) { return hr_shard_pass2(ctxs[r], r ? &edge[r - 1] : nullptr, &part[r]); });
+    if (rc) return rc;
+    hr_shard_partial red{};
+    for (int r = 0; r < active; r++) {  // the "all-reduce": counts and the kept-power sum add, peaks take the maximum
+        for (int b = 0; b < kEbuBins; b++) red.hist[b] += part[r].hist[b];
+        red.sum_kept += part[r].sum_kept;
+        red.n_kept += part[r].n_kept;
+        red.n_blocks += part[r].n_blocks;
+        for (int c = 0; c < HR_MAX_CH; c++) red.peak_per_ch[c] = std::max(red.peak_per_ch[c], part[r].peak_per_ch[c]);
+    }
+    return hr_shard_finish(ctxs[0], &red, track->channels, out);
 }
 
 int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_rate, uint32_t channels, uint64_t frames)

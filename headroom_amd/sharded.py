@@ -28,6 +28,19 @@ def partition_tracks(n_tracks, world, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
+def partition_tracks_by_bytes(sizes, world):
+    """Longest-first greedy assignment: track i of `sizes` bytes goes to the rank with the least
+    bytes so far, so that ranks with unequal tracks finish together.  Returns a list of index lists, one per
+    rank, each in input order."""
+    load = [0] * world
+    mine = [[] for _ in range(world)]
+    for i in sorted(range(len(sizes)), key=lambda j: (-sizes[j], j)):
+        r = min(range(world), key=lambda q: (load[q], q))
+        load[r] += sizes[i]
+        mine[r].append(i)
+    return [sorted(m) for m in mine]
+
+
 def cut_stream(frames, sample_rate, world):
     """Frame offsets [c_0 = 0, ..., c_world = frames] of `world` time shards: every cut is a multiple of
     the hop, every shard but the last holds at least MIN_SHARD_HOPS whole hops.  Ranks that would get

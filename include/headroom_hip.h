@@ -155,6 +155,12 @@ int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left_edge, hr_shard_partial
 /* Gating from the all-reduced partial. */
 int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *reduced, int channels, hr_result *out);
 
+/* The same inside ONE process: n_ctx contexts (one per GPU; HR_GATE_EBUR128 or HR_GATE_LOUDNORM, same modes in
+ * all of them) each take one time shard of `track`, the exchange steps above run on the host.  Host PCM, or
+ * device PCM when every context sits on the GPU that holds it.  Streams too short to cut (fewer than six
+ * hops per shard) use fewer contexts.  No counterpart in the reference. */
+int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *track, hr_result *out);
+
 /* Deterministic synthetic PCM written straight into device memory (bench / tests):
  * f32 interleaved, `frames` x `channels`.  Same bits as the oracle's generator. */
 int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_rate,

@@ -79,6 +79,13 @@ def mode_cpu(rank, world):
         sizes = [b - a for a, b in (sharded.partition_tracks(n, world, r) for r in range(world))]
         assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
 
+    # --- unequal tracks: longest-first greedy by bytes; every track exactly once, loads within one track of each other
+    sizes = [((7 * i) % 13 + 1) * 1000 for i in range(41)]
+    parts = sharded.partition_tracks_by_bytes(sizes, world)
+    assert sorted(i for p in parts for i in p) == list(range(41))
+    loads = [sum(sizes[i] for i in p) for p in parts]
+    assert max(loads) - min(loads) <= max(sizes)
+
     # --- stream cuts ------------------------------------------------------------------------------
     fs = 48000
     frames = 4800 * 61 + 1000

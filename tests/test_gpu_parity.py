@@ -342,3 +342,32 @@ def test_golden_vectors_on_gpu(meters, idx):
         li = float.fromhex(exp["integrated_lufs"])
         assert got["integrated_lufs"] == li or abs(got["integrated_lufs"] - li) < 1e-6, (key, got)
         assert [float.hex(float(x)) for x in got["peak_per_ch"]] == exp["peak_per_ch"], (key, got)
+
+
+@pytest.mark.parametrize("gate", ["ebur128", "loudnorm"])
+def test_analyze_stream_sharded_in_process(oracle, meters, gate):
+    """hr_analyze_stream_sharded: BASELINE config 5's shape in one process, here three contexts on one device
+    (host PCM and device PCM), against the unsharded result and the oracle; short streams use fewer shards."""
+    import torch
+    fs = 48000
+    pcm = signals.seeded_noise(314, 4800 * 95 + 2222, 2, -20.0)
+    pcm[fs: 3 * fs] *= 0.01
+    ms = [hr.Meter(gate_mode=GATES[gate]) for _ in range(3)]
+    try:
+        whole = meters(gate).analyze(pcm, fs)
+        ref = oracle.measure(pcm, fs, gate_mode=GATES[gate])
+        dev = torch.from_numpy(pcm).cuda()
+        for spec in (hr.TrackSpec(pcm, fs), hr.TrackSpec(dev, fs)):
+            got = hr.analyze_stream_sharded(ms, spec)
+            assert got["n_blocks"] == whole["n_blocks"] == ref["n_blocks"] and got["n_gated"] == whole["n_gated"]
+            assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
+            assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+            assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+        short = pcm[: 4800 * 8 + 100].copy()  # eight hops: one shard only
+        got = hr.analyze_stream_sharded(ms, hr.TrackSpec(short, fs))
+        ref = oracle.measure(short, fs, gate_mode=GATES[gate])
+        assert got["n_blocks"] == ref["n_blocks"] and abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+        assert got["peak_per_ch"] == ref["peak_per_ch"]
+    finally:
+        for m in ms:
+            m.close()
