@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=1000, help="tracks per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--host-pcm", type=int, default=0, metavar="N",
+                    help="also time N tracks handed over as pinned HOST buffers (PCIe-inclusive; reported beside, never as value)")
     args = ap.parse_args()
 
     import torch
@@ -142,6 +144,24 @@ def main():
             worst_i = max(abs(res[i]["integrated_lufs"] - ref[i]["integrated_lufs"]) for i in range(len(ref)))
             same_tp = all(res[i]["peak_per_ch"] == ref[i]["peak_per_ch"] for i in range(len(ref)))
             line["parity_check"] = {"tracks": len(ref), "max_abs_lufs_diff": worst_i, "true_peak_bit_identical": same_tp}
+        if args.host_pcm > 0:
+            # the boundary also takes host buffers: same tracks from pinned host memory, H2D staging included
+            nh = min(args.host_pcm, n_tracks)
+            host = torch.empty((nh, frames, CH), dtype=torch.float32, pin_memory=True)
+            host.copy_(pcm[:nh])
+            torch.cuda.synchronize()
+            hspecs = [hr.TrackSpec(host[i], FS) for i in range(nh)]
+            hres = meter.analyze_batch(hspecs)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                hres = meter.analyze_batch(hspecs)
+            dt = (time.perf_counter() - t1) / reps
+            assert all(hres[i]["integrated_lufs"] == res[i]["integrated_lufs"] and hres[i]["peak_per_ch"] == res[i]["peak_per_ch"]
+                       for i in range(nh))
+            line["host_pcm"] = {"tracks": nh, "audio_hours_per_s": nh * SECONDS / 3600.0 / dt,
+                                "gb_per_s": nh * frames * CH * 4 / dt / 1e9, "note": "pinned host PCM, staging copies included"}
         print(json.dumps(line), flush=True)
     meter.close()
     if world > 1:
