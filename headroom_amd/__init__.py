@@ -62,9 +62,14 @@ class HrAnalysis(C.Structure):
                 ("effective_gain", C.c_double), ("lossless_gain_steps", C.c_int32), ("status", C.c_int32)]
 
 
+class HrPcmInfo(C.Structure):
+    _fields_ = [("frames", C.c_uint64), ("data_offset", C.c_uint64), ("sample_rate", C.c_uint32), ("channel_mask", C.c_uint32),
+                ("channels", C.c_uint16), ("fmt", C.c_uint16), ("big_endian", C.c_int32)]
+
+
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
-           "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision"]
+           "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file"]
 
 _lib = None
 
@@ -102,6 +107,8 @@ def lib():
     L.hr_shard_pass2.argtypes = [C.c_void_p, C.POINTER(HrShardEdge), C.POINTER(HrShardPartial)]
     L.hr_shard_finish.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.c_int, C.POINTER(HrResult)]
     L.hr_analyze_stream_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(HrTrack), C.POINTER(HrResult)]
+    L.hr_pcm_probe.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(HrPcmInfo)]
+    L.hr_pcm_load_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(HrTrack), C.POINTER(C.c_float)]
     L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hr_strerror.argtypes = [C.c_int]
@@ -274,6 +281,35 @@ class Meter:
         r = HrResult()
         _check(lib().hr_shard_finish(self._h, C.byref(partial), channels, C.byref(r)), "hr_shard_finish")
         return _result_dict(r, channels)
+
+
+def pcm_probe(data):
+    """hr_pcm_probe on a bytes object: (rc, dict of the header fields)."""
+    info = HrPcmInfo()
+    rc = lib().hr_pcm_probe(data, len(data), C.byref(info))
+    return rc, {f: getattr(info, f) for f, _ in HrPcmInfo._fields_}
+
+
+class LoadedFile:
+    """hr_pcm_load_file: a WAV / AIFF file in pinned host memory, usable as a TrackSpec-like object."""
+
+    def __init__(self, path):
+        self._pcm = C.c_void_p()
+        self.c = HrTrack()
+        self.weights = (C.c_float * MAX_CH)()
+        _check(lib().hr_pcm_load_file(os.fsencode(path), C.byref(self._pcm), C.byref(self.c), self.weights), "hr_pcm_load_file")
+        self.channels = self.c.channels
+
+    def close(self):
+        if self._pcm:
+            lib().hr_free_pinned(self._pcm)
+            self._pcm = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def analyze_stream_sharded(meters, spec):

@@ -173,6 +173,29 @@ int hr_last_timing(hr_ctx *ctx, float *total_ms, float *main_kernel_ms);
 
 const char *hr_strerror(int code);
 
+/* ---- PCM container ingest: WAV and AIFF need no decoder -------------------------------
+ * The reference hands every file to `ffmpeg -i <path> -map 0:a:0` (src/analyzer.rs:253-259) and lists wav, aiff
+ * and aif among its lossless extensions (src/scanner.rs:6).  For these containers the first audio stream is
+ * plain PCM: RIFF/WAVE (PCM, IEEE float, WAVE_FORMAT_EXTENSIBLE with its channel mask) and AIFF / AIFF-C
+ * (NONE, twos, sowt, fl32, fl64).  Anything compressed returns HR_ERR_FORMAT and stays with the caller's decoder. */
+typedef struct hr_pcm_info {
+    uint64_t frames;       /* samples per channel                                   */
+    uint64_t data_offset;  /* byte offset of the first sample in the file           */
+    uint32_t sample_rate;
+    uint32_t channel_mask; /* WAVE_FORMAT_EXTENSIBLE dwChannelMask, 0 when absent   */
+    uint16_t channels;
+    uint16_t fmt;          /* HR_FMT_*                                              */
+    int32_t big_endian;    /* samples need a byte swap (AIFF) before the meter      */
+} hr_pcm_info;
+
+/* Parses the container header found in file_bytes[0..n) (the whole file or a prefix that holds the header
+ * chunks).  Host-only: needs no GPU. */
+int hr_pcm_probe(const void *file_bytes, size_t n, hr_pcm_info *info);
+/* Reads `path` into pinned host memory (little endian, ready for hr_analyze_batch), fills `track` (its ch_weight
+ * points at `weights`, HR_MAX_CH floats owned by the caller: FFmpeg's layout weights, from the channel mask when
+ * the file has one).  Free *pcm_out with hr_free_pinned. */
+int hr_pcm_load_file(const char *path, void **pcm_out, hr_track *track, float *weights);
+
 /* ---- host-side mirror of the analyzer's scalar logic (src/analyzer.rs:157-187, :304-326) ---- */
 
 enum { /* GainMethod, src/analyzer.rs:36-50 */

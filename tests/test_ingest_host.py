@@ -1,0 +1,87 @@
+"""WAV / AIFF header parsing (hr_pcm_probe, host only).  Files are built byte by byte in
+tests/containers.py; expectations follow the published container layouts and FFmpeg's demuxer behaviour
+(wavdec.c / aiffdec.c: even chunk padding, data size 0 / 0xFFFFFFFF / overrun = to end of file)."""
+import numpy as np
+import pytest
+
+import containers
+import headroom_amd as hr
+
+FMT = {"s16": hr.FMT_S16, "s24": hr.FMT_S24, "s32": hr.FMT_S32, "f32": hr.FMT_F32, "f64": hr.FMT_F64}
+
+
+def _pcm(frames=1000, ch=2, seed=3):
+    return np.random.default_rng(seed).uniform(-0.9, 0.9, size=(frames, ch))
+
+
+@pytest.mark.parametrize("kind", ["s16", "s24", "s32", "f32", "f64"])
+@pytest.mark.parametrize("ch", [1, 2, 6])
+def test_wav_plain(kind, ch):
+    data, _ = containers.wav_bytes(_pcm(777, ch), 44100, kind)
+    rc, info = hr.pcm_probe(data)
+    assert rc == 0
+    assert (info["frames"], info["sample_rate"], info["channels"], info["fmt"], info["big_endian"]) == (777, 44100, ch, FMT[kind], 0)
+    assert info["data_offset"] == 44 and info["channel_mask"] == 0
+
+
+def test_wav_extensible_mask_and_extra_chunks():
+    junk = (b"LIST", b"INFOISFT" + b"\x05\x00\x00\x00abcde"), (b"bext", b"x" * 13)  # an odd-sized chunk gets a pad byte
+    data, _ = containers.wav_bytes(_pcm(500, 6), 96000, "s24", extensible_mask=0x3F, extra_chunks=junk)
+    rc, info = hr.pcm_probe(data)
+    assert rc == 0 and info["channel_mask"] == 0x3F and info["fmt"] == hr.FMT_S24 and info["frames"] == 500
+    assert data[info["data_offset"] - 8: info["data_offset"] - 4] == b"data"
+
+
+@pytest.mark.parametrize("size", [0, 0xFFFFFFFF, 10 ** 9])
+def test_wav_data_size_unknown_means_to_end_of_file(size):
+    data, _ = containers.wav_bytes(_pcm(321, 2), 48000, "s16", data_size_override=size)
+    rc, info = hr.pcm_probe(data)
+    assert rc == 0 and info["frames"] == 321
+
+
+def test_wav_truncated_file_keeps_whole_frames():
+    data, _ = containers.wav_bytes(_pcm(400, 2), 48000, "s24")
+    rc, info = hr.pcm_probe(data[:-7])  # 7 bytes short: one whole frame (6 B) and a fragment are gone
+    assert rc == 0 and info["frames"] == 398
+
+
+def test_wav_rejects_what_is_not_pcm():
+    data, _ = containers.wav_bytes(_pcm(10, 2), 48000, "s16")
+    bad = bytearray(data)
+    bad[20:22] = (0x55).to_bytes(2, "little")  # WAVE_FORMAT_MPEGLAYER3
+    assert hr.pcm_probe(bytes(bad))[0] == hr.ERR_FORMAT
+    bad = bytearray(data)
+    bad[34:36] = (8).to_bytes(2, "little")  # 8-bit PCM
+    assert hr.pcm_probe(bytes(bad))[0] == hr.ERR_FORMAT
+    assert hr.pcm_probe(b"RIFF\x00\x00\x00\x00WAVE")[0] == hr.ERR_FORMAT
+    assert hr.pcm_probe(b"OggS" + b"\0" * 40)[0] == hr.ERR_FORMAT
+    assert hr.pcm_probe(b"")[0] == hr.ERR_FORMAT
+
+
+@pytest.mark.parametrize("kind,aifc,big", [("s16", None, 1), ("s24", None, 1), ("s32", b"NONE", 1), ("s16", b"twos", 1),
+                                           ("s16", b"sowt", 0), ("s24", b"sowt", 0), ("f32", b"fl32", 1), ("f32", b"FL32", 1),
+                                           ("f64", b"fl64", 1)])
+def test_aiff_variants(kind, aifc, big):
+    data, _ = containers.aiff_bytes(_pcm(640, 2), 44100, kind, aifc=aifc)
+    rc, info = hr.pcm_probe(data)
+    assert rc == 0
+    assert (info["frames"], info["sample_rate"], info["channels"], info["fmt"], info["big_endian"]) == (640, 44100, 2, FMT[kind], big)
+
+
+@pytest.mark.parametrize("fs", [8000, 22050, 44100, 48000, 88200, 96000, 176400, 192000])
+def test_aiff_extended_sample_rate(fs):
+    data, _ = containers.aiff_bytes(_pcm(64, 1), fs, "s16")
+    rc, info = hr.pcm_probe(data)
+    assert rc == 0 and info["sample_rate"] == fs
+
+
+def test_aiff_ssnd_offset_and_chunk_order():
+    data, _ = containers.aiff_bytes(_pcm(100, 2), 48000, "s16", ssnd_offset=6, ssnd_first=True)
+    rc, info = hr.pcm_probe(data)
+    assert rc == 0 and info["frames"] == 100
+    assert data[info["data_offset"] - 6: info["data_offset"]] == b"\xaa" * 6
+
+
+def test_aiff_compressed_is_rejected():
+    data, _ = containers.aiff_bytes(_pcm(10, 2), 44100, "s16", aifc=b"ima4")
+    assert hr.pcm_probe(data)[0] == hr.ERR_FORMAT
