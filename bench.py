@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=1000, help="tracks per GPU (default: BASELINE config 2)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--pcm-format", choices=["f32", "s16"], default="f32",
+                    help="f32 is the BASELINE workload; s16 measures the widening path (a side figure, labelled as such)")
     ap.add_argument("--host-pcm", type=int, default=0, metavar="N",
                     help="also time N tracks handed over as pinned HOST buffers (PCIe-inclusive; reported beside, never as value)")
     args = ap.parse_args()
@@ -82,8 +84,16 @@ def main():
     for i in range(n_tracks):
         meter.synth_fill(pcm[i].data_ptr(), 1000 + rank * n_tracks + i, FS, CH, frames)
     torch.cuda.synchronize()
-    specs = [hr.TrackSpec(pcm[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_F32, frames=frames) for i in range(n_tracks)]
-    bytes_per_step = n_tracks * frames * CH * 4
+    if args.pcm_format == "s16":
+        pcm16 = torch.empty((n_tracks, frames, CH), dtype=torch.int16, device=dev)
+        for i in range(n_tracks):
+            pcm16[i] = torch.clamp(torch.round(pcm[i] * 32768.0), -32768, 32767).to(torch.int16)
+        torch.cuda.synchronize()
+        specs = [hr.TrackSpec(pcm16[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_S16, frames=frames) for i in range(n_tracks)]
+        bytes_per_step = n_tracks * frames * CH * 2
+    else:
+        specs = [hr.TrackSpec(pcm[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_F32, frames=frames) for i in range(n_tracks)]
+        bytes_per_step = n_tracks * frames * CH * 4
 
     def barrier():
         torch.cuda.synchronize()
@@ -126,7 +136,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s 44.1 kHz stereo f32 PCM resident in HBM "
+            "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s 44.1 kHz stereo {args.pcm_format} PCM resident in HBM "
                                    "(BASELINE configs[1]); per-track integrated LUFS (ebur128 gating) + dBTP (192 kHz)",
                        "tracks_per_gpu": n_tracks, "bytes_per_gpu": bytes_per_step, "parallelism": f"track-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -136,7 +146,7 @@ def main():
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32":
             threads = min(16, os.cpu_count() or 1)
             base, ref, cpu_tracks = cpu_baseline(threads, threads)
             line["cpu_baseline"] = base

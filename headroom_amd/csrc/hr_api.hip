@@ -77,7 +77,7 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
 
     // workspace (grow-only)
-    DevBuf tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
@@ -487,6 +487,16 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     return HR_OK;
 }
 
+// A stereo s16 / s24 track is widened to f32 on the device (exactly) so that it takes the fused kernel; the
+// generic kernels, one thread per hop, are two orders of magnitude slower.
+bool widens(const hr_ctx *ctx, const hr_track &t)
+{
+    const uint32_t hop = t.sample_rate / 10;
+    return ctx->cfg.engine != 1 && t.channels == 2 && (t.fmt == HR_FMT_S16 || t.fmt == HR_FMT_S24) && hop >= 64 &&
+           t.frames / hop >= 2;
+}
+size_t widened_bytes(const hr_track &t) { return (t.frames * t.channels * sizeof(float) + 255) / 256 * 256; }
+
 // Stages the host-resident tracks of [begin, end) and measures the group.
 int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t> &idx, hr_result *out)
 {
@@ -502,13 +512,24 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
         stage_need += (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
     }
     if (stage_need && !ctx->stage.ensure(stage_need)) return HR_ERR_OOM;
+    size_t widen_need = 0;
+    std::vector<size_t> woff(idx.size(), 0);
+    for (size_t k = 0; k < idx.size(); k++)
+        if (widens(ctx, tracks[idx[k]])) { woff[k] = widen_need; widen_need += widened_bytes(tracks[idx[k]]); }
+    if (widen_need && !ctx->widened.ensure(widen_need)) return HR_ERR_OOM;
     for (size_t k = 0; k < idx.size(); k++) {
-        const hr_track &t = tracks[idx[k]];
+        hr_track t = tracks[idx[k]];
         const void *dev = t.pcm;
         if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
             dev = static_cast<char *>(ctx->stage.p) + off[k];
             const size_t bytes = t.frames * t.channels * fmt_bytes(t.fmt);
             if (bytes) HIPCHK(hipMemcpyAsync(const_cast<void *>(dev), t.pcm, bytes, hipMemcpyHostToDevice, st));
+        }
+        if (widens(ctx, t)) {
+            float *w = reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]);
+            launch_widen_pcm(t.fmt, dev, w, t.frames * t.channels, st);
+            dev = w;
+            t.fmt = HR_FMT_F32;
         }
         const int ri = rate_index(ctx, t.sample_rate);
         if (ri < 0) return ri;
@@ -587,7 +608,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
-                      &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->widened, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -617,9 +638,11 @@ int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *o
     ctx->last_total_ms = ctx->last_main_ms = 0;
     const double ninf = -std::numeric_limits<double>::infinity();
     std::vector<size_t> cur;
-    size_t cur_bytes = 0;
+    size_t cur_bytes = 0, cur_widened = 0;
+    const size_t widen_limit = 16 * ctx->cfg.stage_bytes;  // f32 copies of integer tracks (16 GiB by default)
     int fatal = HR_OK;
     auto flush = [&]() {
+        cur_widened = 0;
         if (cur.empty() || fatal) { cur.clear(); cur_bytes = 0; return; }
         const int rc = analyze_group(ctx, tracks, cur, out);
         if (rc) {
@@ -637,9 +660,11 @@ int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *o
         if (v) { out[i].status = v; continue; }
         const size_t bytes = (tracks[i].flags & HR_TRACK_DEVICE_PCM)
                                  ? 0 : tracks[i].frames * tracks[i].channels * fmt_bytes(tracks[i].fmt) + 256;
-        if (!cur.empty() && cur_bytes + bytes > ctx->cfg.stage_bytes) flush();
+        const size_t wbytes = widens(ctx, tracks[i]) ? widened_bytes(tracks[i]) : 0;
+        if (!cur.empty() && (cur_bytes + bytes > ctx->cfg.stage_bytes || cur_widened + wbytes > widen_limit)) flush();
         cur.push_back(i);
         cur_bytes += bytes;
+        cur_widened += wbytes;
     }
     flush();
     return fatal;

@@ -50,6 +50,8 @@ struct SynthPar {
     uint32_t burst_len;
 };
 void synth_params(uint64_t seed, uint32_t fs, uint64_t frames, SynthPar *p);
+// fmt HR_FMT_S16 (1) or HR_FMT_S24 (2) -> f32 (dst 16-byte aligned), exact
+void launch_widen_pcm(int fmt, const void *src, float *dst, uint64_t n_samples, hipStream_t st);
 void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channels, uint64_t frames, hipStream_t st);
 
 }  // namespace hr

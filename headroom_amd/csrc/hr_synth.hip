@@ -91,4 +91,42 @@ void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channel
     hipLaunchKernelGGL(k_synth, dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st, out, seed, p, channels, frames);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Integer PCM -> f32, exactly: a 16- or 24-bit sample times 2^-15 / 2^-23 is representable in f32 (24-bit
+// significand) and is the very value the generic kernels compute in f64, so a widened s16 / s24 stereo track can
+// take the fused f32 kernel with bit-identical results.  (s32 and f64 do not fit f32 and stay generic.)
+// ---------------------------------------------------------------------------------------------
+template <int FMT>
+__global__ void __launch_bounds__(256) k_widen_pcm(const uint8_t *__restrict__ src, float *__restrict__ dst, uint64_t n_samples)
+{
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256 * 4;
+    for (uint64_t i = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n_samples; i += stride) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const uint64_t k = i + j < n_samples ? i + j : n_samples - 1;
+            if constexpr (FMT == 1) {
+                v[j] = static_cast<float>(reinterpret_cast<const int16_t *>(src)[k]) * (1.0f / 32768.0f);
+            } else {
+                const uint8_t *b = src + 3 * k;
+                const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 8 | static_cast<uint32_t>(b[1]) << 16 |
+                                                       static_cast<uint32_t>(b[2]) << 24) >> 8;
+                v[j] = static_cast<float>(x) * (1.0f / 8388608.0f);
+            }
+        }
+        if (i + 4 <= n_samples) *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+        else
+            for (int j = 0; i + j < n_samples; j++) dst[i + j] = v[j];
+    }
+}
+
+void launch_widen_pcm(int fmt, const void *src, float *dst, uint64_t n_samples, hipStream_t st)
+{
+    if (!n_samples) return;
+    uint64_t blocks = (n_samples + 1023) / 1024;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+    if (fmt == 1) k_widen_pcm<1><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(static_cast<const uint8_t *>(src), dst, n_samples);
+    else k_widen_pcm<2><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(static_cast<const uint8_t *>(src), dst, n_samples);
+}
+
 }  // namespace hr

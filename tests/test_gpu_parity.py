@@ -371,3 +371,30 @@ def test_analyze_stream_sharded_in_process(oracle, meters, gate):
     finally:
         for m in ms:
             m.close()
+
+
+@pytest.mark.parametrize("fs", [44100, 48000])
+def test_integer_stereo_tracks_take_the_fused_kernel(oracle, meters, fs):
+    """s16 / s24 stereo is widened to f32 on the device (exactly) and measured by the fused kernel: same numbers
+    as the generic kernels and the oracle, from host and device buffers, also when the widened copies do not fit
+    one group."""
+    import torch
+    pcm = signals.seeded_noise(77 + fs, fs * 4 + 1001, 2, -11.0)
+    pcm[: fs] *= 0.02
+    s16 = signals.to_s16(pcm)
+    s24 = signals.to_s24_bytes(pcm)
+    ref16 = oracle.measure(s16, fs)
+    ref24 = oracle.measure(s24, fs, channels=2, fmt=hr.FMT_S24)
+    for engine in (0, 1):
+        m = meters(engine=engine)
+        got = m.analyze_batch([hr.TrackSpec(s16, fs), hr.TrackSpec(s24, fs, channels=2, fmt=hr.FMT_S24),
+                               hr.TrackSpec(torch.from_numpy(s16).cuda(), fs),
+                               hr.TrackSpec(torch.from_numpy(s24).cuda(), fs, channels=2, fmt=hr.FMT_S24)])
+        for g, ref in zip(got, (ref16, ref24, ref16, ref24)):
+            assert g["status"] == 0 and g["n_blocks"] == ref["n_blocks"] and g["n_gated"] == ref["n_gated"]
+            assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+            assert g["peak_per_ch"] == ref["peak_per_ch"]
+    with hr.Meter(stage_bytes=1 << 20) as small:  # 16 MiB of widened copies per group: the six tracks need three groups
+        got = small.analyze_batch([hr.TrackSpec(torch.from_numpy(s16).cuda(), fs) for _ in range(6)])
+        assert all(g["peak_per_ch"] == ref16["peak_per_ch"] and abs(g["integrated_lufs"] - ref16["integrated_lufs"]) < 1e-6
+                   for g in got)
