@@ -69,7 +69,8 @@ class HrPcmInfo(C.Structure):
 
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
-           "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file"]
+           "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
+           "hr_report_csv_header", "hr_report_csv_row"]
 
 _lib = None
 
@@ -109,6 +110,8 @@ def lib():
     L.hr_analyze_stream_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(HrTrack), C.POINTER(HrResult)]
     L.hr_pcm_probe.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(HrPcmInfo)]
     L.hr_pcm_load_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(HrTrack), C.POINTER(C.c_float)]
+    L.hr_report_csv_header.argtypes = [C.c_char_p, C.c_size_t]
+    L.hr_report_csv_row.argtypes = [C.c_char_p, C.POINTER(HrAnalysis), C.c_char_p, C.c_size_t]
     L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hr_strerror.argtypes = [C.c_int]
@@ -281,6 +284,20 @@ class Meter:
         r = HrResult()
         _check(lib().hr_shard_finish(self._h, C.byref(partial), channels, C.byref(r)), "hr_shard_finish")
         return _result_dict(r, channels)
+
+
+def report_csv(rows):
+    """rows: (filename, analysis dict as returned by gain_decision) -> the CSV text of src/report.rs generate_csv."""
+    buf = C.create_string_buffer(4096)
+    n = lib().hr_report_csv_header(buf, len(buf))
+    assert n > 0
+    out = buf.raw[:n].decode()
+    for name, a in rows:
+        rec = HrAnalysis(**{f: a[f] for f, _ in HrAnalysis._fields_})
+        n = lib().hr_report_csv_row(name.encode(), C.byref(rec), buf, len(buf))
+        _check(n if n < 0 else OK, "hr_report_csv_row")
+        out += buf.raw[:n].decode()
+    return out
 
 
 def pcm_probe(data):

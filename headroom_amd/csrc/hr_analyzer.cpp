@@ -4,6 +4,9 @@
 // check and gain decision).  GAIN_STEP is mp3rgain::GAIN_STEP_DB (src/analyzer.rs:29; mp3rgain 2.9.1,
 // Cargo.lock:961-964; README.md:282 states the value: 1.5 dB, fixed by the MP3/AAC global_gain step).
 #include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
 
 #include "../../include/headroom_hip.h"
 
@@ -65,4 +68,65 @@ extern "C" int hr_gain_decision(double input_i, double input_tp, int kind, int h
     }
     out->status = HR_OK;
     return HR_OK;
+}
+
+// ---- report rows: src/report.rs:29-59 (CSV header and record), labels src/analyzer.rs:80-100 ---------------------
+namespace {
+const char *format_label(int m)  // GainMethod::format_label
+{
+    switch (m) {
+    case HR_GAIN_MP3_LOSSLESS: case HR_GAIN_MP3_REENCODE: return "MP3";
+    case HR_GAIN_AAC_LOSSLESS: case HR_GAIN_AAC_REENCODE: return "AAC";
+    case HR_GAIN_FFMPEG_LOSSLESS: return "Lossless";
+    default: return "-";
+    }
+}
+const char *method_label(int m)  // GainMethod::method_label
+{
+    switch (m) {
+    case HR_GAIN_FFMPEG_LOSSLESS: return "ffmpeg";
+    case HR_GAIN_MP3_LOSSLESS: case HR_GAIN_AAC_LOSSLESS: return "native";
+    case HR_GAIN_MP3_REENCODE: case HR_GAIN_AAC_REENCODE: return "re-encode";
+    default: return "none";
+    }
+}
+// the csv crate's default quoting (QuoteStyle::Necessary): quote a field that holds the delimiter, a quote or a
+// line break, doubling the quotes inside
+void csv_field(std::string &o, const char *f)
+{
+    if (!std::strpbrk(f, ",\"\r\n")) { o += f; return; }
+    o += '"';
+    for (const char *p = f; *p; p++) { if (*p == '"') o += '"'; o += *p; }
+    o += '"';
+}
+int emit(const std::string &s, char *buf, size_t cap)
+{
+    if (!buf || cap < s.size() + 1) return HR_ERR_TOO_LARGE;
+    std::memcpy(buf, s.c_str(), s.size() + 1);
+    return static_cast<int>(s.size());
+}
+}  // namespace
+
+extern "C" int hr_report_csv_header(char *buf, size_t cap)
+{
+    return emit("Filename,Format,Bitrate (kbps),LUFS,True Peak (dBTP),Target (dBTP),Headroom (dB),Method,Effective Gain (dB)\n", buf, cap);
+}
+
+extern "C" int hr_report_csv_row(const char *filename, const hr_analysis *a, char *buf, size_t cap)
+{
+    if (!filename || !a) return HR_ERR_INVALID;
+    char num[64];
+    std::string o;
+    csv_field(o, filename);
+    o += ',';
+    o += format_label(a->gain_method);
+    o += ',';
+    if (a->has_bitrate) { std::snprintf(num, sizeof num, "%u", a->bitrate_kbps); o += num; } else o += '-';
+    // Rust's {:.1} / {:+.1} and C's %.1f / %+.1f both round the exact binary value to nearest, ties to even
+    std::snprintf(num, sizeof num, ",%.1f,%.1f,%.1f,%+.1f,", a->input_i, a->input_tp, a->target_tp, a->headroom);
+    o += num;
+    o += method_label(a->gain_method);
+    std::snprintf(num, sizeof num, ",%+.1f\n", a->effective_gain);
+    o += num;
+    return emit(o, buf, cap);
 }

@@ -223,6 +223,13 @@ typedef struct hr_analysis { /* AudioAnalysis minus the path strings, src/analyz
 int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
                      const hr_tp_target *mode, hr_analysis *out);
 
+/* One line of the CSV report, src/report.rs:29-59: the header record, and the record of one analysed file
+ * (labels: GainMethod::format_label / method_label, src/analyzer.rs:80-100; numbers with one decimal, headroom and
+ * gain signed; fields quoted as the csv crate does by default).  Return the length written (without the NUL), or
+ * HR_ERR_TOO_LARGE when `cap` is too small. */
+int hr_report_csv_header(char *buf, size_t cap);
+int hr_report_csv_row(const char *filename, const hr_analysis *a, char *buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -144,3 +144,33 @@ def test_tp_screen_tiles_and_error_bound(fs):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", os.path.join(ROOT, "tests", "cpu_tp_tiles_check.cpp"),
                            os.path.join(ROOT, "headroom_amd", "csrc", "hr_tables.cpp"), "-o", exe])
     subprocess.check_call([exe, str(fs)], stdout=subprocess.DEVNULL)
+
+
+# ---- CSV report rows: src/report.rs:29-59 ----------------------------------------------------------------------
+
+def test_report_csv_rows_follow_report_rs():
+    rows = []
+    rc, a = hr.gain_decision(-14.04, -3.26)                                        # lossless, headroom 2.76
+    rows.append(("track one.flac", a))
+    rc, a = hr.gain_decision(-9.96, -5.0, kind=hr.KIND_MP3, bitrate_kbps=320)      # 3 native steps
+    rows.append(("b,with comma.mp3", a))
+    rc, a = hr.gain_decision(-12.0, -1.9, kind=hr.KIND_AAC, bitrate_kbps=192, split=(-0.5, -1.0))  # re-encode, low target
+    rows.append(('say "hi".m4a', a))
+    rc, a = hr.gain_decision(-8.0, -0.52)                                          # nothing to gain
+    rows.append(("loud.wav", a))
+    text = hr.report_csv(rows)
+    assert text.splitlines() == [
+        "Filename,Format,Bitrate (kbps),LUFS,True Peak (dBTP),Target (dBTP),Headroom (dB),Method,Effective Gain (dB)",
+        "track one.flac,Lossless,-,-14.0,-3.3,-0.5,+2.8,ffmpeg,+2.8",
+        '"b,with comma.mp3",MP3,320,-10.0,-5.0,-0.5,+4.5,native,+4.5',
+        '"say ""hi"".m4a",AAC,192,-12.0,-1.9,-1.0,+0.9,re-encode,+0.9',
+        "loud.wav,-,-,-8.0,-0.5,-0.5,+0.0,none,+0.0",
+    ]
+    assert text.endswith("\n")
+
+
+def test_report_csv_row_buffer_too_small():
+    rc, a = hr.gain_decision(-14.0, -3.0)
+    rec = hr.HrAnalysis(**{f: a[f] for f, _ in hr.HrAnalysis._fields_})
+    buf = C.create_string_buffer(8)
+    assert hr.lib().hr_report_csv_row(b"x.wav", C.byref(rec), buf, len(buf)) == hr.ERR_TOO_LARGE
