@@ -85,6 +85,7 @@ struct hr_ctx {
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<WorkItem> h_ovf_items;
     bool serial_tail = false;  // HR_SERIAL_TAIL=1 (timing experiments): tail kernels before the fused kernel, not beside it
+    bool split = false;  // HR_FUSED_SPLIT=1: k_fused_split (K-weighting and true peak in separate waves) instead of k_fused_f32s
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
 
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -382,7 +383,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             fsc.cand_cnt = fs.cand_cnt + off;
             const bool tp = cls < kFusedClasses - 1;
             launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
-                              ctx->peaks.as<unsigned long long>(), tp ? v0 : (v0 == 3 ? 3 : 1), cls, dbg, st);
+                              ctx->peaks.as<unsigned long long>(),
+                              tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1), cls, dbg, st);
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -581,6 +583,7 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     ctx->cfg = c;
     if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
     if (const char *ab = std::getenv("HR_ABLATE")) ctx->ablate = std::atoi(ab);
+    if (const char *sp = std::getenv("HR_FUSED_SPLIT")) ctx->split = std::atoi(sp) != 0;
     if (const char *se = std::getenv("HR_SERIAL_TAIL")) ctx->serial_tail = std::atoi(se) != 0;
     if (c.stream) ctx->stream = static_cast<hipStream_t>(c.stream);
     else {

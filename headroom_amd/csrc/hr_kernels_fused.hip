@@ -31,6 +31,7 @@
 // src/analyzer.rs:253-267); SURVEY.md Appendix A.2 / A.4.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "hr_device.hpp"
@@ -725,6 +726,409 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     }
 }
 
+// ---- k_fused_split: the same pass with the two halves of the work in SEPARATE waves -------------------------------
+// A workgroup is eight waves = four pairs; a pair owns one item (64 rows).  Wave p (0..3) of a pair K-weights
+// (f64 VALU only), wave p+4 screens the true peak (f16 MFMA + f32 VALU); both read the SAME 8 KiB LDS image of the
+// piece, which each of them half fills by LDS-DMA, so the PCM is still read from HBM once.  The piece buffer is
+// in a ring of four buffers (pieces k+1 .. k+3 are in flight while piece k is consumed), so one s_barrier per step is enough.  The two
+// instruction streams are independent: the SIMD's own arbiter overlaps the f64 chain of one wave with the matrix
+// work of the other, instead of a hand-interleaved schedule inside one wave.  Arithmetic (operation order of the
+// K-weighting, screen bounds, candidate lists) is exactly that of k_fused_f32s: the records and peaks are
+// bit-identical.
+// Measured (profiles/README.md, round 1): NOT faster -- 4.70-4.79 ms against 4.52 ms for 200 tracks, with one
+// 148 KiB workgroup per CU; deeper piece rings change nothing.  It is therefore opt-in (HR_FUSED_SPLIT=1) and kept
+// as the vehicle for per-role timing: wave_map bit 0 = pairing of waves (0: w / w+4, 1: 2p / 2p+1), bit 1 = the
+// K-weighting waves only move data, bit 2 = the true-peak waves only move data (results are wrong with bits 1, 2).
+constexpr int kSplitLds = 16 * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
+
+template <int MT, bool SMALL>
+__global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict__ tracks,
+                                                     const RateDev *__restrict__ rates,
+                                                     const FusedItem *__restrict__ items, HopRec *__restrict__ recs,
+                                                     uint2 *__restrict__ cands, unsigned *__restrict__ cand_cnt,
+                                                     unsigned *__restrict__ tpb, unsigned *__restrict__ overflow,
+                                                     unsigned long long *__restrict__ peaks, int wave_map)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // kSplitLds
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int pair = wave_map ? wave >> 1 : wave & 3;
+    const bool tp_role = wave_map ? (wave & 1) != 0 : wave >= 4;
+    const uint32_t item_idx = blockIdx.x * 4 + pair;
+    const FusedItem it = items[item_idx];
+    const TrackDesc &t = tracks[it.track];
+    const RateDev &r = rates[t.rate_idx];
+    const uint32_t hop = t.hop;
+    const int T = static_cast<int>((hop + 15) / 16);
+    const int n_rows = static_cast<int>(it.n_rows);
+    const int last_row = n_rows > 0 ? n_rows - 1 : 0;
+    const int row = lane < n_rows ? lane : last_row;
+    const uint64_t h = it.first_hop + row;
+    const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * 8ull;
+    char *pbuf = smem + pair * 4 * kPieceLds;  // [4][8 KiB]: piece k lives in buffer k mod 4
+    char *abuf = smem + 16 * kPieceLds;        // [2][9 KiB]
+    char *gbuf = abuf + 2 * kCoefLds;          // [2][1 KiB]
+    const char *gsrc = reinterpret_cast<const char *>(r.g);
+    const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
+    const int T_full = static_cast<int>(hop / 16), rem = static_cast<int>(hop % 16);
+    const int k_short = r.q_n0 < hop ? static_cast<int>(r.q_n0 / 16) : T + 1;
+
+    // this wave's half of the piece DMA: instructions jbase .. jbase+3 of the eight (slots 8j .. 8j+7 each)
+    const int jbase = tp_role ? 4 : 0;
+    unsigned dma_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int slot = 8 * (jbase + j) + (lane >> 3);
+        const int chunk = (lane & 7) ^ ((slot >> 1) & 7);
+        const int srow = slot < n_rows ? slot : last_row;
+        dma_off[j] = static_cast<unsigned>(srow) * hop * 8u + static_cast<unsigned>(chunk) * 16u;
+    }
+    const unsigned rd_swz = (lane >> 1) & 7;
+    auto issue_piece = [&](int k) {
+        const char *src = wave_base + static_cast<size_t>(k) * 128;
+        char *dst = pbuf + (k & 3) * kPieceLds + jbase * 1024;
+#pragma unroll
+        for (int j = 0; j < 4; j++) dma16(src, dma_off[j], dst + j * 1024);
+    };
+
+    // The piece is read with hidden LDS reads too: piece k+1 is still in flight when piece k is consumed, and the
+    // compiler would wait for every outstanding DMA in front of an LDS read it can see.
+    unsigned rd_off[8];
+#pragma unroll
+    for (int c = 0; c < 8; c++) rd_off[c] = lds_addr(pbuf) + static_cast<unsigned>(lane) * 128u + ((static_cast<unsigned>(c) ^ rd_swz) * 16u);
+    float4 v[8];
+    auto read_piece = [&](int k) {
+        uint4v u[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) u[c] = lds_ld128(rd_off[c] + static_cast<unsigned>(k & 3) * kPieceLds, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) : : "memory");
+#pragma unroll
+        for (int c = 0; c < 8; c++)
+            v[c] = make_float4(__uint_as_float(u[c][0]), __uint_as_float(u[c][1]), __uint_as_float(u[c][2]), __uint_as_float(u[c][3]));
+    };
+    // everything this wave has in flight except the newest piece (its four DMAs are always the last ones issued)
+    auto wait_step = [&](int k) {
+        if (k + 2 <= T) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (k < T) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+
+    // ---- prologue: the 16 frames in front of the row
+    {
+        const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * 8u);
+        if (h > 0) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(rowp - 32 + 4 * c);
+        } else if (t.left_tail) {
+#pragma unroll
+            for (int c = 0; c < 8; c++)
+                v[c] = make_float4(static_cast<float>(t.left_tail[(2 * c) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c) * 2 + 1]),
+                                   static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 1]));
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const float2 a = *reinterpret_cast<const float2 *>(rowp + 2 * (16 - 2 * c));
+                const float2 b = *reinterpret_cast<const float2 *>(rowp + 2 * (15 - 2 * c));
+                v[c] = make_float4(a.x, a.y, b.x, b.y);
+            }
+        }
+    }
+    const bool have_history = h > 0 || t.left_tail;  // else: start of the stream, the K-weighting starts from silence
+
+    if (!tp_role) {
+        // ================================ K-weighting wave ================================
+        const KCoef kc = r.k;
+        KState ks[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) ks[c] = KState{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (have_history) {
+            ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
+            ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
+        }
+        if (pair == 0) dma16(gsrc, lane16, gbuf);
+        issue_piece(0);
+        issue_piece(1);
+        issue_piece(2);
+
+        auto kw_step = [&](int k, auto short_c) {
+            constexpr bool SHORT = decltype(short_c)::value;
+            wait_step(k);
+            __builtin_amdgcn_s_barrier();
+            const char *my_lds = pbuf + (k & 3) * kPieceLds + lane * 128;
+            read_piece(k);
+            if (rem && k == T_full) {
+                const char *gk = gbuf + (k & 1) * kCarryLds;
+                for (int i = 0; i < rem; i++) {
+                    const float2 x = *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8);
+                    if constexpr (!SHORT) {
+                        const G4 g4 = lds_g4(gk + i * 32);
+                        kw_sample(ks[0], kc, x.x, g4);
+                        kw_sample(ks[1], kc, x.y, g4);
+                    } else {
+                        const double2 g = *reinterpret_cast<const double2 *>(gk + i * 32 + 16);
+                        kw_sample_short(ks[0], kc, x.x, g.x, g.y);
+                        kw_sample_short(ks[1], kc, x.y, g.x, g.y);
+                    }
+                }
+            }
+            if (k < T && pair == 0) dma16(gsrc + static_cast<size_t>(k + 1) * 512, lane16, gbuf + ((k + 1) & 1) * kCarryLds);
+            if (k + 3 <= T) issue_piece(k + 3);
+            if (k < T_full && !(wave_map & 2)) {
+                const unsigned g_at = lds_addr(gbuf) + static_cast<unsigned>(k & 1) * kCarryLds;  // broadcast reads
+                struct GC { uint4v r[4]; };
+                auto load_gc = [&](int c) {
+                    GC o;
+                    if constexpr (!SHORT) {
+                        o.r[0] = lds_ld128(g_at, (2 * c) * 32);
+                        o.r[1] = lds_ld128(g_at, (2 * c) * 32 + 16);
+                        o.r[2] = lds_ld128(g_at, (2 * c + 1) * 32);
+                        o.r[3] = lds_ld128(g_at, (2 * c + 1) * 32 + 16);
+                    } else {
+                        o.r[1] = lds_ld128(g_at, (2 * c) * 32 + 16);
+                        o.r[3] = lds_ld128(g_at, (2 * c + 1) * 32 + 16);
+                        o.r[0] = o.r[2] = uint4v{0, 0, 0, 0};
+                    }
+                    return o;
+                };
+                auto wait_gc = [&](GC &g) {
+                    if constexpr (!SHORT) lds_wait(g.r[0], g.r[1], g.r[2], g.r[3]);
+                    else lds_wait(g.r[1], g.r[3]);
+                };
+                GC gcur = load_gc(0);
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    wait_gc(gcur);
+                    GC gnext = gcur;
+                    if (c + 1 < 8) gnext = load_gc(c + 1);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        const float x = i == 0 ? v[c].x : i == 1 ? v[c].y : i == 2 ? v[c].z : v[c].w;
+                        const double2 g23 = as_double2(gcur.r[i < 2 ? 1 : 3]);
+                        if constexpr (!SHORT) {
+                            const double2 g01 = as_double2(gcur.r[i < 2 ? 0 : 2]);
+                            kw_sample(ks[i & 1], kc, x, G4{g01.x, g01.y, g23.x, g23.y});
+                        } else {
+                            kw_sample_short(ks[i & 1], kc, x, g23.x, g23.y);
+                        }
+                    }
+                    gcur = gnext;
+                }
+            }
+        };
+        const int k_split = k_short < T + 1 ? k_short : T + 1;
+        for (int k = 0; k < k_split; k++) kw_step(k, std::false_type{});
+        if (k_split <= T) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                ks[c].q0 -= fma(r.q_ab[0][0], ks[c].q2, r.q_ab[0][1] * ks[c].q3);
+                ks[c].q1 -= fma(r.q_ab[1][0], ks[c].q2, r.q_ab[1][1] * ks[c].q3);
+            }
+        }
+        for (int k = k_split; k < T + 1; k++) kw_step(k, std::true_type{});
+        if (lane < n_rows) {
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                if (k_short <= T) {
+                    ks[c].q0 += fma(r.q_ab[0][0], ks[c].q2, r.q_ab[0][1] * ks[c].q3);
+                    ks[c].q1 += fma(r.q_ab[1][0], ks[c].q2, r.q_ab[1][1] * ks[c].q3);
+                }
+                HopRec &o = recs[t.rec_base + (kPreRec + h) * 2 + c];
+                o.e0 = ks[c].e0;
+                o.q[0] = ks[c].q0; o.q[1] = ks[c].q1; o.q[2] = ks[c].q2; o.q[3] = ks[c].q3;
+                o.s[0] = ks[c].y1; o.s[1] = ks[c].y1 - ks[c].y2; o.s[2] = ks[c].z1; o.s[3] = ks[c].z1 - ks[c].z2;
+            }
+        }
+        return;
+    }
+
+    // ================================ true-peak wave ================================
+    // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
+#pragma unroll
+    for (int i = 0; i < 3 * MT; i++) *reinterpret_cast<uint4v *>(abuf + i * 1024 + lane * 16) = uint4v{0, 0, 0, 0};
+
+    uint4v hist[3][2][2];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+            for (int n = 0; n < 2; n++) hist[a][c][n] = uint4v{0, 0, 0, 0};
+    float s_lane[2] = {0.0f, 0.0f}, alb[2] = {0.0f, 0.0f};
+    float S_u[2] = {-1.0f, -1.0f}, A_u[2] = {0.0f, 0.0f}, lb[2] = {0.0f, 0.0f};
+    float thr_l[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; c++) thr_l[c][0] = thr_l[c][1] = __builtin_inff();
+    unsigned n_cand = 0;
+    uint2 *__restrict__ my_cands = cands + static_cast<size_t>(item_idx) * kCandCap;
+
+    auto make_frags = [&](auto slot_c) {
+        constexpr int slot = decltype(slot_c)::value;
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
+            s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
+        }
+        unsigned f[2][8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            f[0][c] = pk_f16(v[c].x, v[c].z);
+            f[1][c] = pk_f16(v[c].y, v[c].w);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(f[ch][j], f[ch][j + 4], false, false);
+                hist[slot][ch][0][j] = sw[0];
+                hist[slot][ch][1][j] = sw[1];
+            }
+    };
+    make_frags(std::integral_constant<int, 2>{});  // the prologue piece is "piece -1"
+
+    const int NP = r.tp_np;
+    int pat = 0;
+    // this wave's share (chunks i with i mod 4 == pair) of the coefficients of the tile that step k+1 screens
+    auto issue_coeff = [&](int pattern, int k, int kmod3) {
+        const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + static_cast<size_t>(pattern) * MT * 3 * 1024;
+        char *dst = abuf + ((k + 1) & 1) * kCoefLds;
+#pragma unroll
+        for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+            for (int ksx = 0; ksx < 3; ksx++)
+                if (((mt * 3 + ksx) & 3) == pair)
+                    dma16(asrc + (mt * 3 + ksx) * 1024, lane16, dst + (mt * 3 + (kmod3 + 2 + ksx) % 3) * 1024);
+    };
+    issue_piece(0);
+    issue_piece(1);
+    issue_piece(2);
+
+    auto tp_step = [&](int k, auto slot_c) {
+        constexpr int KK = decltype(slot_c)::value;  // k mod 3
+        wait_step(k);
+        __builtin_amdgcn_s_barrier();
+        read_piece(k);
+        if (k < T) {
+            issue_coeff(pat, k, KK);
+            pat = pat + 1 == NP ? 0 : pat + 1;
+        }
+        if (k + 3 <= T) issue_piece(k + 3);
+        if (wave_map & 4) return;
+        make_frags(slot_c);
+        {
+            const float over = fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1]));
+            const bool stale = over > 0.0f;
+            if (__ballot(stale) != 0ull) {
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++) {
+                    S_u[ch] = wave_max_f32(s_lane[ch]);
+                    A_u[ch] = wave_max_f32(alb[ch]);
+                    const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
+                    lb[ch] = fmaxf(lb[ch], fmaxf(S_u[ch], A_u[ch] - err));
+                    const float thr = fmaxf(lb[ch] - err, 1e-30f);
+                    thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
+                    thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
+                }
+            }
+        }
+        // screen of tile k-1 (pieces k-2, k-1, k)
+        float m0[MT][2][2];
+        {
+            const unsigned a_at = lds_addr(abuf) + static_cast<unsigned>(k & 1) * kCoefLds + lane16;
+            uint4v af[3];
+#pragma unroll
+            for (int k3 = 0; k3 < 3; k3++) af[k3] = lds_ld128(a_at, k3 * 1024);
+            lds_wait(af[0], af[1], af[2]);
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++) {
+                uint4v an[3] = {af[0], af[1], af[2]};
+                if (mt + 1 < MT) {
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; k3++) an[k3] = lds_ld128(a_at, ((mt + 1) * 3 + k3) * 1024);
+                }
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++) {
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        floatx16 acc = {0};
+#pragma unroll
+                        for (int k3 = 0; k3 < 3; k3++)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
+                        float m = fmaxf(fmaxf(fabsf(acc[0]), fabsf(acc[1])), fmaxf(fabsf(acc[2]), fabsf(acc[3])));
+                        if (!(SMALL && mt == MT - 1)) {
+#pragma unroll
+                            for (int i = 4; i < 16; i += 2) m = fmaxf(fmaxf(fabsf(acc[i]), fabsf(acc[i + 1])), m);
+                        }
+                        m0[mt][ch][nt] = m;
+                    }
+                    alb[ch] = fmaxf(fmaxf(m0[mt][ch][0], m0[mt][ch][1]), alb[ch]);
+                }
+                if (mt + 1 < MT) {
+                    lds_wait(an[0], an[1], an[2]);
+#pragma unroll
+                    for (int k3 = 0; k3 < 3; k3++) af[k3] = an[k3];
+                }
+            }
+        }
+        float margin = -__builtin_inff();
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                float mm = m0[0][ch][nt];
+#pragma unroll
+                for (int mt = 1; mt < MT; mt++) mm = fmaxf(mm, m0[mt][ch][nt]);
+                margin = fmaxf(margin, mm - thr_l[ch][nt]);
+            }
+        const unsigned long long any = __ballot(margin >= 0.0f);
+        if (any != 0ull) {  // wave-uniform, rare
+#pragma unroll
+            for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                    for (int nt = 0; nt < 2; nt++) {
+                        const bool flag = m0[mt][ch][nt] >= thr_l[ch][nt];
+                        const unsigned long long mask = __ballot(flag);
+                        if (mask == 0ull) continue;
+                        const unsigned slot = n_cand + __builtin_amdgcn_mbcnt_hi(static_cast<unsigned>(mask >> 32),
+                                                                                  __builtin_amdgcn_mbcnt_lo(static_cast<unsigned>(mask), 0));
+                        if (flag && slot < kCandCap)
+                            my_cands[slot] = make_uint2(static_cast<unsigned>(ch) | static_cast<unsigned>(32 * nt + (lane & 31)) << 1 |
+                                                            static_cast<unsigned>(mt) << 7 | static_cast<unsigned>(lane >> 5) << 9 |
+                                                            static_cast<unsigned>(k - 1) << 10,
+                                                        __float_as_uint(m0[mt][ch][nt]));
+                        n_cand += static_cast<unsigned>(__popcll(mask));
+                    }
+        }
+    };
+    for (int k = 0; k < T + 1; k += 3) {
+        tp_step(k, std::integral_constant<int, 0>{});
+        if (k + 1 < T + 1) tp_step(k + 1, std::integral_constant<int, 1>{});
+        if (k + 2 < T + 1) tp_step(k + 2, std::integral_constant<int, 2>{});
+    }
+    {
+        float Sf[2], Af[2];
+#pragma unroll
+        for (int c = 0; c < 2; c++) {
+            Sf[c] = wave_max_f32(s_lane[c]);
+            Af[c] = wave_max_f32(alb[c]);
+            lb[c] = fmaxf(lb[c], fmaxf(Sf[c], Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
+        }
+        if (lane == 0) {
+            cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
+            if (n_cand > kCandCap || Sf[0] >= kF16Safe || Sf[1] >= kF16Safe) overflow[it.track] = 1u;
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(lb[c]));
+                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(Sf[c]));
+                if (Sf[c] > 0.0f)
+                    atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
+                              static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(Sf[c]))));
+            }
+        }
+    }
+}
+
 // Exact evaluation of the candidates that can still be the maximum.  One workgroup per wave item of the
 // fused kernel, one thread per candidate slot.
 __global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__restrict__ tracks,
@@ -792,6 +1196,19 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
 
 int fused_tp_class(int tp_mt, int tp_last_rows) { return (tp_mt - 1) * 2 + (tp_last_rows <= 8 ? 1 : 0); }
 
+template <int MT, bool SMALL>
+static void launch_split_case(dim3 grid, hipStream_t st, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
+                              HopRec *recs, uint2 *cands, const FusedScratch &fs, unsigned long long *peaks)
+{
+    // more than 64 KiB of dynamic LDS has to be asked for once per kernel
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_split<MT, SMALL>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds);
+    (void)attr;
+    static const int wave_map = std::getenv("HR_WAVE_MAP") ? std::atoi(std::getenv("HR_WAVE_MAP")) : 0;
+    k_fused_split<MT, SMALL><<<grid, dim3(512), kSplitLds, st>>>(tracks, rates, items, recs, cands, fs.cand_cnt, fs.tpb,
+                                                                  fs.overflow, peaks, wave_map);
+}
+
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
                        HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int tp_class, int dbg,
                        hipStream_t st)
@@ -802,6 +1219,18 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
     // the stream rate depends on the bytes in flight)
     const size_t lds = variant == 3 ? 4 * kPieceLds : kGroupLds;
     uint2 *cands = static_cast<uint2 *>(fs.cands);
+    if (variant == 4) {  // full pass, K-weighting and true peak in separate waves
+        switch (tp_class) {
+        case 0: launch_split_case<1, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
+        case 1: launch_split_case<1, true>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
+        case 2: launch_split_case<2, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
+        case 3: launch_split_case<2, true>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
+        case 4: launch_split_case<3, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
+        default: launch_split_case<3, true>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
+        }
+        k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
+        return;
+    }
     switch (variant) {
     case 1: launch_class<true, false>(0, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;
     case 2: launch_class<false, true>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;

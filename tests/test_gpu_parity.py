@@ -398,3 +398,18 @@ def test_integer_stereo_tracks_take_the_fused_kernel(oracle, meters, fs):
         got = small.analyze_batch([hr.TrackSpec(torch.from_numpy(s16).cuda(), fs) for _ in range(6)])
         assert all(g["peak_per_ch"] == ref16["peak_per_ch"] and abs(g["integrated_lufs"] - ref16["integrated_lufs"]) < 1e-6
                    for g in got)
+
+
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_split_wave_kernel_is_bit_identical(oracle, meters, fs, monkeypatch):
+    """HR_FUSED_SPLIT=1 (k_fused_split: K-weighting and true peak in separate waves) gives the oracle's results too."""
+    monkeypatch.setenv("HR_FUSED_SPLIT", "1")
+    m = hr.Meter(device=0)
+    try:
+        pcm = signals.seeded_noise(31 + fs, fs * 9 + 321, 2, -12.0)
+        pcm[: fs] *= 0.003
+        got, ref = check_against_oracle(oracle, m, pcm, fs)
+        base = meters().analyze(pcm, fs)
+        assert got["integrated_lufs"] == base["integrated_lufs"] and got["peak_per_ch"] == base["peak_per_ch"]
+    finally:
+        m.close()
