@@ -77,7 +77,7 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
 
     // workspace (grow-only)
-    DevBuf widened, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, parents_d, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
@@ -188,6 +188,7 @@ struct Group {
     std::vector<TrackDesc> descs;
     std::vector<int> fmts;  // per desc
     uint64_t rec_slots = 0, hop_slots = 0, blk_slots = 0;  // totals: (hop, channel) records / sums, blocks
+    std::vector<uint32_t> parents;  // descriptors with role 1 (measured through stereo planes)
 };
 
 void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bool stream_start, bool stream_end,
@@ -241,7 +242,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0);
     for (size_t i = 0; i < nt; i++) {
         const TrackDesc &d = g.descs[i];
-        const bool ok = ctx->cfg.engine != 1 && d.fmt == HR_FMT_F32 && d.ch == 2 && d.n_hops >= 2 && d.hop >= 64 &&
+        const bool ok = d.role != 1 && ctx->cfg.engine != 1 && d.fmt == HR_FMT_F32 && d.ch == 2 && d.n_hops >= 2 && d.hop >= 64 &&
                         (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
         fkw[i] = ok;
         ftp[i] = ok && do_peaks && ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[d.rate_idx].tp_atab != nullptr;
@@ -289,7 +290,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     for (int f = 0; f < 5; f++) {
         hop_span[f].off = items.size();
         for (size_t i = 0; i < nt; i++) {
-            if (g.fmts[i] != f) continue;
+            if (g.fmts[i] != f || g.descs[i].role == 1) continue;
             if (fkw[i]) continue;  // fused tracks: only the last hop is left, see tail_span
             for (uint64_t h = 0; h < g.descs[i].n_hops; h += 256)
                 items.push_back({static_cast<uint32_t>(i), 0, h});
@@ -306,6 +307,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     comb_span.off = items.size();
     for (size_t i = 0; i < nt; i++) {
         const auto &d = g.descs[i];
+        if (d.role == 1) continue;
         const uint64_t pairs = (d.n_hops + (d.blk_first < 0 ? kPreHop : 0)) * d.ch;
         for (uint64_t p = 0; p < pairs; p += 256) items.push_back({static_cast<uint32_t>(i), 0, p});
     }
@@ -317,7 +319,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             pk_span[f][kind].off = items.size();
             if (do_peaks)
                 for (size_t i = 0; i < nt; i++) {
-                    if (g.fmts[i] != f) continue;
+                    if (g.fmts[i] != f || g.descs[i].role == 1) continue;
                     const bool plain = (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0) ||
                                        (ctx->cfg.tp_mode == HR_TP_BS1770 && g.descs[i].fs >= 192000);
                     if (plain != (kind == 1)) continue;
@@ -394,6 +396,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     if (do_combine)
         launch_hop_combine(dt, dr, di + comb_span.off, static_cast<uint32_t>(comb_span.n), ctx->recs.as<HopRec>(),
                            ctx->hop_sums.as<double>(), st);
+    if (do_combine && !g.parents.empty()) {
+        rc = upload(ctx->parents_d, g.parents.data(), g.parents.size() * sizeof(uint32_t), st);
+        if (rc) return rc;
+        launch_gather_planes(dt, ctx->parents_d.as<uint32_t>(), static_cast<uint32_t>(g.parents.size()), ctx->hop_sums.as<double>(), st);
+    }
     HIPCHK(hipGetLastError());
     return HR_OK;
 }
@@ -489,15 +496,55 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     return HR_OK;
 }
 
-// A stereo s16 / s24 track is widened to f32 on the device (exactly) so that it takes the fused kernel; the
-// generic kernels, one thread per hop, are two orders of magnitude slower.
-bool widens(const hr_ctx *ctx, const hr_track &t)
+// Every f32 / s16 / s24 track that is not already stereo f32 is split on the device into stereo f32 planes (exactly)
+// so that it takes the fused kernel: mono, 5.1, 7.1, integer stereo.  The generic kernels, one thread per hop, are two
+// orders of magnitude slower.  s32 / f64 samples do not fit f32 and stay generic.
+bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = nullptr)
 {
     const uint32_t hop = t.sample_rate / 10;
-    return ctx->cfg.engine != 1 && t.channels == 2 && (t.fmt == HR_FMT_S16 || t.fmt == HR_FMT_S24) && hop >= 64 &&
-           t.frames / hop >= 2;
+    if (ctx->cfg.engine == 1 || hop < 64 || t.frames / hop < 2 || hop * 8ull * 64 >= 0xffffffffull) return false;
+    if (t.fmt != HR_FMT_F32 && t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) return false;
+    if (t.fmt == HR_FMT_F32 && t.channels == 2) return false;  // the fused kernel reads it as it is
+    const void *p = (t.flags & HR_TRACK_DEVICE_PCM) ? t.pcm : dev_or_null;  // staged copies are 256-byte aligned
+    return (reinterpret_cast<uintptr_t>(p) & 3) == 0;
 }
-size_t widened_bytes(const hr_track &t) { return (t.frames * t.channels * sizeof(float) + 255) / 256 * 256; }
+size_t plane_floats(const hr_track &t) { return (t.frames * 2 + 63) / 64 * 64; }
+size_t split_bytes(const hr_track &t) { return plane_floats(t) * sizeof(float) * ((t.channels + 1) / 2); }
+
+// Adds one track to the group (PCM at `dev` on the device); a split track becomes a parent descriptor followed by its
+// plane descriptors in `plane_mem` (split_bytes(t) of 256-byte aligned device memory).  Returns the index of the
+// descriptor that carries the track's results, or a negative error.
+int add_track(hr_ctx *ctx, Group &g, const hr_track &t, const void *dev, float *plane_mem, bool do_split)
+{
+    const int ri = rate_index(ctx, t.sample_rate);
+    if (ri < 0) return ri;
+    const int own = static_cast<int>(g.descs.size());
+    add_desc(g, t, dev, ri, true, true, false, t.frames, ctx->cfg.tp_mode);
+    if (!do_split) return own;
+    const size_t pf = plane_floats(t);
+    launch_split_planes(t.fmt, dev, plane_mem, t.frames, t.channels, pf, ctx->stream);
+    g.descs[own].role = 1;
+    g.descs[own].first_plane = static_cast<uint32_t>(own + 1);
+    g.parents.push_back(static_cast<uint32_t>(own));
+    hr_track pt = t;
+    pt.channels = 2;
+    pt.fmt = HR_FMT_F32;
+    pt.ch_weight = nullptr;
+    for (int p = 0; p < (t.channels + 1) / 2; p++) {
+        add_desc(g, pt, plane_mem + p * pf, ri, true, true, false, t.frames, ctx->cfg.tp_mode);
+        g.descs.back().role = 2;
+    }
+    return own;
+}
+
+// peak bit patterns of the track whose results live in descriptor `di`
+void track_peaks(const Group &g, const std::vector<unsigned long long> &pk, int di, unsigned long long *out)
+{
+    const TrackDesc &d = g.descs[di];
+    for (int c = 0; c < kMaxCh; c++) out[c] = 0;
+    for (int c = 0; c < d.ch; c++)
+        out[c] = d.role == 1 ? pk[(d.first_plane + c / 2) * kMaxCh + (c & 1)] : pk[static_cast<size_t>(di) * kMaxCh + c];
+}
 
 // Stages the host-resident tracks of [begin, end) and measures the group.
 int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t> &idx, hr_result *out)
@@ -516,26 +563,21 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     if (stage_need && !ctx->stage.ensure(stage_need)) return HR_ERR_OOM;
     size_t widen_need = 0;
     std::vector<size_t> woff(idx.size(), 0);
+    std::vector<uint8_t> sp(idx.size(), 0);
     for (size_t k = 0; k < idx.size(); k++)
-        if (widens(ctx, tracks[idx[k]])) { woff[k] = widen_need; widen_need += widened_bytes(tracks[idx[k]]); }
+        if ((sp[k] = splits(ctx, tracks[idx[k]]))) { woff[k] = widen_need; widen_need += split_bytes(tracks[idx[k]]); }
     if (widen_need && !ctx->widened.ensure(widen_need)) return HR_ERR_OOM;
+    std::vector<int> desc_of(idx.size(), 0);
     for (size_t k = 0; k < idx.size(); k++) {
-        hr_track t = tracks[idx[k]];
+        const hr_track &t = tracks[idx[k]];
         const void *dev = t.pcm;
         if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
             dev = static_cast<char *>(ctx->stage.p) + off[k];
             const size_t bytes = t.frames * t.channels * fmt_bytes(t.fmt);
             if (bytes) HIPCHK(hipMemcpyAsync(const_cast<void *>(dev), t.pcm, bytes, hipMemcpyHostToDevice, st));
         }
-        if (widens(ctx, t)) {
-            float *w = reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]);
-            launch_widen_pcm(t.fmt, dev, w, t.frames * t.channels, st);
-            dev = w;
-            t.fmt = HR_FMT_F32;
-        }
-        const int ri = rate_index(ctx, t.sample_rate);
-        if (ri < 0) return ri;
-        add_desc(g, t, dev, ri, true, true, false, t.frames, ctx->cfg.tp_mode);
+        desc_of[k] = add_track(ctx, g, t, dev, reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]), sp[k] != 0);
+        if (desc_of[k] < 0) return desc_of[k];
     }
     int rc = run_measure(ctx, g, true);
     if (rc) return rc;
@@ -553,7 +595,11 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_total_ms += ms;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_main_ms += ms;
-    for (size_t k = 0; k < nt; k++) fill_result(ctx, outs[k], &pk[k * kMaxCh], tracks[idx[k]].channels, &out[idx[k]]);
+    for (size_t k = 0; k < idx.size(); k++) {
+        unsigned long long tpk[kMaxCh];
+        track_peaks(g, pk, desc_of[k], tpk);
+        fill_result(ctx, outs[desc_of[k]], tpk, tracks[idx[k]].channels, &out[idx[k]]);
+    }
     return HR_OK;
 }
 
@@ -611,7 +657,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
-                      &ctx->widened, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->widened, &ctx->parents_d, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -663,7 +709,7 @@ int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *o
         if (v) { out[i].status = v; continue; }
         const size_t bytes = (tracks[i].flags & HR_TRACK_DEVICE_PCM)
                                  ? 0 : tracks[i].frames * tracks[i].channels * fmt_bytes(tracks[i].fmt) + 256;
-        const size_t wbytes = widens(ctx, tracks[i]) ? widened_bytes(tracks[i]) : 0;
+        const size_t wbytes = splits(ctx, tracks[i]) ? split_bytes(tracks[i]) : 0;
         if (!cur.empty() && (cur_bytes + bytes > ctx->cfg.stage_bytes || cur_widened + wbytes > widen_limit)) flush();
         cur.push_back(i);
         cur_bytes += bytes;
@@ -690,14 +736,15 @@ int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint
         dev = ctx->stage.p;
         if (bytes) HIPCHK(hipMemcpyAsync(ctx->stage.p, track->pcm, bytes, hipMemcpyHostToDevice, st));
     }
-    const int ri = rate_index(ctx, track->sample_rate);
-    if (ri < 0) return ri;
-    add_desc(g, *track, dev, ri, true, true, false, track->frames, ctx->cfg.tp_mode);
+    const bool sp = splits(ctx, *track);
+    if (sp && !ctx->widened.ensure(split_bytes(*track))) return HR_ERR_OOM;
+    const int own = add_track(ctx, g, *track, dev, ctx->widened.as<float>(), sp);
+    if (own < 0) return own;
     int rc = run_measure(ctx, g, false);
     if (rc) return rc;
     rc = run_gating(ctx, g, false);
     if (rc) return rc;
-    const TrackDesc &d = g.descs[0];
+    const TrackDesc &d = g.descs[own];
     if (n_hops) *n_hops = d.n_hops;
     if (n_blocks) *n_blocks = d.n_blocks;
     if (hop_sums) {

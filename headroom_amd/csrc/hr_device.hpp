@@ -54,7 +54,9 @@ struct TrackDesc {
     uint8_t stream_start;  // frame 0 is the start of the stream (swr start reflection / zero history)
     uint8_t stream_end;    // last frame is the end of the stream (no resampler flush: last 16 positions dropped)
     uint8_t tp_enabled;    // resampler produces output at all (stream >= 33 frames)
-    uint8_t pad;
+    uint8_t role;          // 0 ordinary track; 1 parent of stereo planes (measured through them: no work items of its
+                           // own, only hop-sum slots and gating); 2 stereo plane of a parent
+    uint32_t first_plane;  // role 1: index of the first of its (ch+1)/2 consecutive plane descriptors
     float w[kMaxCh];
 };
 

@@ -20,6 +20,8 @@ void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
                        const double *ln_bounds, TrackOut *outs, hipStream_t st);
+// hop sums of the stereo planes of a split track -> the track's own (hop, channel) slots; one workgroup per parent
+void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
 // tp_kind: 0 swr192k, 1 bs1770, 2 sample peak; every item covers `span` (multiple of 256) positions, or item.pad
 // positions when that is non-zero (swr192k only)
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
@@ -50,8 +52,10 @@ struct SynthPar {
     uint32_t burst_len;
 };
 void synth_params(uint64_t seed, uint32_t fs, uint64_t frames, SynthPar *p);
-// fmt HR_FMT_S16 (1) or HR_FMT_S24 (2) -> f32 (dst 16-byte aligned), exact
-void launch_widen_pcm(int fmt, const void *src, float *dst, uint64_t n_samples, hipStream_t st);
+// interleaved f32 / s16 / s24 (fmt 0 / 1 / 2; src dword aligned) of any channel count -> (channels+1)/2 stereo f32
+// planes, plane p at dst + p*plane_floats (16-byte aligned), exact
+void launch_split_planes(int fmt, const void *src, float *dst, uint64_t frames, uint32_t channels, uint64_t plane_floats,
+                         hipStream_t st);
 void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channels, uint64_t frames, hipStream_t st);
 
 }  // namespace hr

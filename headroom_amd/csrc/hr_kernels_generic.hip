@@ -550,6 +550,25 @@ void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const Wor
     hipLaunchKernelGGL(k_hop_combine, dim3(n_items), dim3(256), 0, st, tracks, rates, items, recs, hop_sums);
 }
 
+// A track measured through stereo planes (TrackDesc::role 1): its hop sums are those of its planes' channels.
+__global__ void __launch_bounds__(256) k_gather_planes(const TrackDesc *__restrict__ tracks, const uint32_t *__restrict__ parents,
+                                                       double *__restrict__ hop_sums)
+{
+    const TrackDesc &p = tracks[parents[blockIdx.x]];
+    const uint64_t C = p.ch, total = p.n_hops * C;
+    for (uint64_t i = threadIdx.x; i < total; i += 256) {
+        const uint64_t h = i / C, c = i % C;
+        const TrackDesc &q = tracks[p.first_plane + c / 2];
+        hop_sums[p.hop_base + (kPreHop + h) * C + c] = hop_sums[q.hop_base + (kPreHop + h) * 2 + (c & 1)];
+    }
+}
+
+void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st)
+{
+    if (!n_parents) return;
+    hipLaunchKernelGGL(k_gather_planes, dim3(n_parents), dim3(256), 0, st, tracks, parents, hop_sums);
+}
+
 void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
                        const double *ln_bounds, double *block_powers, uint32_t *hist, TrackOut *outs, hipStream_t st)
 {

@@ -92,41 +92,71 @@ void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channel
 }
 
 // ---------------------------------------------------------------------------------------------
-// Integer PCM -> f32, exactly: a 16- or 24-bit sample times 2^-15 / 2^-23 is representable in f32 (24-bit
-// significand) and is the very value the generic kernels compute in f64, so a widened s16 / s24 stereo track can
-// take the fused f32 kernel with bit-identical results.  (s32 and f64 do not fit f32 and stay generic.)
+// Interleaved PCM of any channel count -> stereo f32 planes, exactly.  Plane p holds channels 2p and 2p+1 as
+// interleaved f32 pairs (the second of an odd last channel is zero), which is the layout the fused kernel reads: a
+// mono, 5.1 or 7.1 track becomes 1, 3 or 4 stereo pseudo-tracks.  A 16- or 24-bit sample times 2^-15 / 2^-23 is
+// representable in f32 (24-bit significand) and is the very value the generic kernels compute in f64, so the
+// results stay bit-identical.  (s32 and f64 do not fit f32 and stay on the generic kernels.)
+// One workgroup moves 256 frames: the interleaved bytes come in as coalesced dwords through LDS (a 5.1 s24 frame is
+// 18 bytes: no lane-aligned view of it exists), the planes go out as one float2 per lane.
 // ---------------------------------------------------------------------------------------------
-template <int FMT>
-__global__ void __launch_bounds__(256) k_widen_pcm(const uint8_t *__restrict__ src, float *__restrict__ dst, uint64_t n_samples)
+template <int FMT>  // 0 f32, 1 s16, 2 s24 (HR_FMT_*)
+__global__ void __launch_bounds__(256) k_split_planes(const uint8_t *__restrict__ src, float *__restrict__ dst, uint64_t frames,
+                                                      uint32_t channels, uint64_t plane_floats)
 {
-    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * 256 * 4;
-    for (uint64_t i = (static_cast<uint64_t>(blockIdx.x) * 256 + threadIdx.x) * 4; i < n_samples; i += stride) {
-        float v[4];
+    constexpr uint32_t B = FMT == 0 ? 4 : FMT == 1 ? 2 : 3;
+    __shared__ __attribute__((aligned(16))) uint32_t lds[256 * kMaxCh * 4 / 4];
+    const uint32_t fb = channels * B;  // frame bytes
+    const uint64_t total_bytes = frames * fb;
+    const uint32_t planes = (channels + 1) / 2;
+    for (uint64_t f0 = static_cast<uint64_t>(blockIdx.x) * 256; f0 < frames; f0 += static_cast<uint64_t>(gridDim.x) * 256) {
+        const uint64_t byte0 = f0 * fb;  // a multiple of 4: the source is dword aligned (checked by the host)
+        const uint64_t nbytes = (total_bytes - byte0 < 256ull * fb) ? total_bytes - byte0 : 256ull * fb;
+        const uint32_t full = static_cast<uint32_t>(nbytes / 4), tail = static_cast<uint32_t>(nbytes % 4);
+        for (uint32_t i = threadIdx.x; i < full; i += 256) lds[i] = reinterpret_cast<const uint32_t *>(src + byte0)[i];
+        if (threadIdx.x < tail) reinterpret_cast<uint8_t *>(lds)[full * 4 + threadIdx.x] = src[byte0 + full * 4 + threadIdx.x];
+        __syncthreads();
+        const uint64_t f = f0 + threadIdx.x;
+        if (f < frames) {
+            const uint8_t *fp = reinterpret_cast<const uint8_t *>(lds) + threadIdx.x * fb;
+            for (uint32_t p = 0; p < planes; p++) {
+                float v[2] = {0.0f, 0.0f};
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            const uint64_t k = i + j < n_samples ? i + j : n_samples - 1;
-            if constexpr (FMT == 1) {
-                v[j] = static_cast<float>(reinterpret_cast<const int16_t *>(src)[k]) * (1.0f / 32768.0f);
-            } else {
-                const uint8_t *b = src + 3 * k;
-                const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 8 | static_cast<uint32_t>(b[1]) << 16 |
-                                                       static_cast<uint32_t>(b[2]) << 24) >> 8;
-                v[j] = static_cast<float>(x) * (1.0f / 8388608.0f);
+                for (uint32_t j = 0; j < 2; j++) {
+                    const uint32_t c = 2 * p + j;
+                    if (c >= channels) break;
+                    const uint8_t *b = fp + c * B;
+                    if constexpr (FMT == 0) {
+                        uint32_t u = static_cast<uint32_t>(b[0]) | static_cast<uint32_t>(b[1]) << 8 | static_cast<uint32_t>(b[2]) << 16 |
+                                     static_cast<uint32_t>(b[3]) << 24;
+                        v[j] = __uint_as_float(u);
+                    } else if constexpr (FMT == 1) {
+                        const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 16 | static_cast<uint32_t>(b[1]) << 24) >> 16;
+                        v[j] = static_cast<float>(x) * (1.0f / 32768.0f);
+                    } else {
+                        const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 8 | static_cast<uint32_t>(b[1]) << 16 |
+                                                               static_cast<uint32_t>(b[2]) << 24) >> 8;
+                        v[j] = static_cast<float>(x) * (1.0f / 8388608.0f);
+                    }
+                }
+                *reinterpret_cast<float2 *>(dst + p * plane_floats + f * 2) = make_float2(v[0], v[1]);
             }
         }
-        if (i + 4 <= n_samples) *reinterpret_cast<float4 *>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
-        else
-            for (int j = 0; i + j < n_samples; j++) dst[i + j] = v[j];
+        __syncthreads();
     }
 }
 
-void launch_widen_pcm(int fmt, const void *src, float *dst, uint64_t n_samples, hipStream_t st)
+void launch_split_planes(int fmt, const void *src, float *dst, uint64_t frames, uint32_t channels, uint64_t plane_floats,
+                         hipStream_t st)
 {
-    if (!n_samples) return;
-    uint64_t blocks = (n_samples + 1023) / 1024;
+    if (!frames) return;
+    uint64_t blocks = (frames + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-    if (fmt == 1) k_widen_pcm<1><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(static_cast<const uint8_t *>(src), dst, n_samples);
-    else k_widen_pcm<2><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(static_cast<const uint8_t *>(src), dst, n_samples);
+    const dim3 grid(static_cast<uint32_t>(blocks)), block(256);
+    const uint8_t *s = static_cast<const uint8_t *>(src);
+    if (fmt == 0) k_split_planes<0><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
+    else if (fmt == 1) k_split_planes<1><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
+    else k_split_planes<2><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
 }
 
 }  // namespace hr
