@@ -57,9 +57,11 @@ def main():
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--pcm-format", choices=["f32", "s16"], default="f32",
                     help="f32 is the BASELINE workload; s16 measures the widening path (a side figure, labelled as such)")
-    ap.add_argument("--workload", choices=["config2", "config4"], default="config2",
+    ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2",
                     help="config2 = the BASELINE bench workload; config4 = 96 kHz 24-bit 5.1 tracks (a side figure: split into "
-                         "stereo f32 planes on the device, then the same fused kernel)")
+                         "stereo f32 planes on the device, then the same fused kernel); config5 = one 10-hour 48 kHz stereo stream, "
+                         "whole and as 8 time shards on this one device (a side figure)")
+    ap.add_argument("--hours", type=float, default=10.0, help="config5: length of the stream")
     ap.add_argument("--host-pcm", type=int, default=0, metavar="N",
                     help="also time N tracks handed over as pinned HOST buffers (PCIe-inclusive; reported beside, never as value)")
     args = ap.parse_args()
@@ -84,6 +86,10 @@ def main():
     meter = hr.Meter(device=local, engine=args.engine)
     if args.workload == "config4":
         run_config4(args, meter, dev, n_tracks, rank)
+        meter.close()
+        return
+    if args.workload == "config5":
+        run_config5(args, meter, dev, local)
         meter.close()
         return
     frames = FS * SECONDS
@@ -216,6 +222,40 @@ def run_config4(args, meter, dev, n_tracks, rank):
                       "config": {"workload": f"{n_tracks} x 180 s 96 kHz 5.1 s24 tracks resident in HBM (BASELINE configs[3]); side figure",
                                  "bytes_per_gpu": nbytes},
                       "hbm_gbs_whole_step": nbytes / dt / 1e9, "sample_result": res[0]}), flush=True)
+
+
+def run_config5(args, meter, dev, local):
+    """BASELINE configs[4] on ONE device: a single long 48 kHz stereo f32 stream, analysed whole (one track) and as 8
+    time shards through hr_analyze_stream_sharded (8 contexts on this device: carry hand-off, boundary blocks, halos
+    and the histogram reduction are all exercised; only the GPUs are not distinct)."""
+    import torch
+
+    import headroom_amd as hr
+    fs, ch = 48000, 2
+    frames = int(args.hours * 3600) * fs
+    pcm = torch.empty((frames, ch), dtype=torch.float32, device=dev)
+    meter.synth_fill(pcm.data_ptr(), 77, fs, ch, frames)
+    torch.cuda.synchronize()
+    spec = hr.TrackSpec(pcm.data_ptr(), fs, channels=ch, fmt=hr.FMT_F32, frames=frames)
+    out = {}
+    shards = [hr.Meter(device=local, engine=args.engine) for _ in range(8)]
+    for name, fn in (("whole", lambda: meter.analyze_batch([spec])[0]), ("sharded8", lambda: hr.analyze_stream_sharded(shards, spec))):
+        for _ in range(args.warmup):
+            res = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = fn()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / args.steps
+        out[name] = {"ms": dt * 1e3, "audio_hours_per_s": args.hours / dt, "gb_per_s": frames * ch * 4 / dt / 1e9, "result": res}
+    for m in shards:
+        m.close()
+    a, b = out["whole"]["result"], out["sharded8"]["result"]
+    out["agree"] = {"n_blocks": a["n_blocks"] == b["n_blocks"], "lufs_diff": abs(a["integrated_lufs"] - b["integrated_lufs"]),
+                    "peaks_identical": a["peak_per_ch"] == b["peak_per_ch"]}
+    out["config"] = {"workload": f"one {args.hours:g} h 48 kHz stereo f32 stream resident in HBM (BASELINE configs[4]), 1 device; side figure"}
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
