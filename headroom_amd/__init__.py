@@ -40,7 +40,9 @@ class HrTrack(C.Structure):
 class HrResult(C.Structure):
     _fields_ = [("integrated_lufs", C.c_double), ("true_peak_dbtp", C.c_double), ("rel_threshold_lufs", C.c_double),
                 ("n_blocks", C.c_uint64), ("n_gated", C.c_uint64), ("peak_per_ch", C.c_double * MAX_CH),
-                ("status", C.c_int32), ("reserved", C.c_int32)]
+                ("status", C.c_int32), ("reserved", C.c_int32),
+                ("loudness_range_lu", C.c_double), ("lra_low_lufs", C.c_double), ("lra_high_lufs", C.c_double),
+                ("lra_threshold_lufs", C.c_double), ("max_momentary_lufs", C.c_double), ("max_shortterm_lufs", C.c_double)]
 
 
 class HrShardEdge(C.Structure):
@@ -140,7 +142,10 @@ def device_count():
 def _result_dict(r, channels):
     return {"integrated_lufs": r.integrated_lufs, "true_peak_dbtp": r.true_peak_dbtp,
             "rel_threshold_lufs": r.rel_threshold_lufs, "n_blocks": int(r.n_blocks), "n_gated": int(r.n_gated),
-            "peak_per_ch": [r.peak_per_ch[i] for i in range(channels)], "status": int(r.status)}
+            "peak_per_ch": [r.peak_per_ch[i] for i in range(channels)], "status": int(r.status),
+            "loudness_range_lu": r.loudness_range_lu, "lra_low_lufs": r.lra_low_lufs, "lra_high_lufs": r.lra_high_lufs,
+            "lra_threshold_lufs": r.lra_threshold_lufs, "max_momentary_lufs": r.max_momentary_lufs,
+            "max_shortterm_lufs": r.max_shortterm_lufs}
 
 
 class TrackSpec:

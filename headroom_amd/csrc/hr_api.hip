@@ -415,17 +415,42 @@ int run_gating(hr_ctx *ctx, Group &g, bool finalize)
     const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
     launch_block_hist(dt, nt, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
                       ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->outs.as<TrackOut>(), st);
-    if (finalize)
+    if (finalize) {
         launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
                           ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
                           ctx->outs.as<TrackOut>(), st);
+        launch_range_stats(dt, nt, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
+                           ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->outs.as<TrackOut>(), st);
+    }
     HIPCHK(hipGetLastError());
     return HR_OK;
 }
 
-void fill_result(const hr_ctx *ctx, const TrackOut &o, const unsigned long long *pk, int channels, hr_result *r)
+void fill_result(const hr_ctx *ctx, const TrackOut &o, const unsigned long long *pk, int channels, hr_result *r,
+                 bool have_range = true)
 {
     const double ninf = -std::numeric_limits<double>::infinity();
+    const double nan = std::numeric_limits<double>::quiet_NaN();
+    r->loudness_range_lu = r->lra_low_lufs = r->lra_high_lufs = r->lra_threshold_lufs = nan;
+    r->max_momentary_lufs = r->max_shortterm_lufs = nan;
+    if (have_range) {
+        const bool ln = ctx->cfg.gate_mode == HR_GATE_LOUDNORM;
+        auto loud = [&](double e) { return ln ? 10.0 * (std::log(e) / std::log(10.0)) - 0.691 : -0.691 + 10.0 * std::log10(e); };
+        r->loudness_range_lu = 0.0;
+        if (o.st_rel_energy > 0.0) r->lra_threshold_lufs = ln ? loud(0.01 * o.st_rel_energy) : loud(o.st_rel_energy) + (-20.0);
+        if (o.lra_low_bin >= 0) {
+            if (ln) {
+                r->lra_low_lufs = loud(loudnorm_bin_energy()[o.lra_low_bin]);
+                r->lra_high_lufs = loud(loudnorm_bin_energy()[o.lra_high_bin]);
+            } else {
+                r->lra_low_lufs = static_cast<double>(o.lra_low_bin) / 100.0 + (-70.0);
+                r->lra_high_lufs = static_cast<double>(o.lra_high_bin) / 100.0 + (-70.0);
+            }
+            r->loudness_range_lu = r->lra_high_lufs - r->lra_low_lufs;
+        }
+        r->max_momentary_lufs = o.n_blocks ? loud(o.max_m_power) : ninf;
+        r->max_shortterm_lufs = o.n_shortterm ? loud(o.max_s_power) : ninf;
+    }
     r->n_blocks = o.n_blocks;
     r->n_gated = o.n_kept;
     r->integrated_lufs = ninf;
@@ -705,6 +730,8 @@ int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *o
     for (size_t i = 0; i < n; i++) {
         std::memset(&out[i], 0, sizeof out[i]);
         out[i].integrated_lufs = out[i].true_peak_dbtp = out[i].rel_threshold_lufs = ninf;
+        out[i].loudness_range_lu = out[i].lra_low_lufs = out[i].lra_high_lufs = out[i].lra_threshold_lufs =
+            out[i].max_momentary_lufs = out[i].max_shortterm_lufs = std::numeric_limits<double>::quiet_NaN();
         const int v = validate_track(ctx, tracks[i]);
         if (v) { out[i].status = v; continue; }
         const size_t bytes = (tracks[i].flags & HR_TRACK_DEVICE_PCM)
@@ -954,7 +981,7 @@ int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_r
     unsigned long long pk[kMaxCh] = {0};
     for (int c = 0; c < channels; c++) std::memcpy(&pk[c], &red->peak_per_ch[c], sizeof(double));
     std::memset(out, 0, sizeof *out);
-    fill_result(ctx, o, pk, channels, out);
+    fill_result(ctx, o, pk, channels, out, false);
     return HR_OK;
 }
 

@@ -81,6 +81,11 @@ struct TrackOut {  // what the finalize kernel hands to the host
     uint64_t n_kept;
     uint64_t n_gated_final;  // blocks in the final integration
     uint64_t n_blocks;
+    // k_range_stats (whole tracks only): loudness range and the maxima of the 400 ms / 3 s powers
+    double st_rel_energy;    // mean power of the short-term blocks behind the LRA gate (before the -20 LU); 0: none
+    double max_m_power, max_s_power;  // 0: no block
+    uint64_t n_shortterm;
+    int32_t lra_low_bin, lra_high_bin;  // histogram bins of the 10 % / 95 % points; -1: no block passed
 };
 
 }  // namespace hr

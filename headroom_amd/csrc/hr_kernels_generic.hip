@@ -410,6 +410,175 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
+// Loudness range + maximum momentary / short-term power.  One workgroup per (whole) track; the short-term
+// histogram lives in LDS.  gate modes 0, 1: f_ebur128.c (i3000 histogram, gate_update with -20 LU, its 10 % / 95 %
+// counting rule); mode 2: libavfilter/ebur128.c ff_ebur128_loudness_range (3 s blocks every second, 1000 bins).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ double block_reduce_max(double v, double *sh)
+{
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
+        if (tid < s) sh[tid] = sh[tid + s] > sh[tid] ? sh[tid + s] : sh[tid];
+        __syncthreads();
+    }
+    const double r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict__ tracks, int gate_mode,
+                                                     const double *__restrict__ hop_sums,
+                                                     const double *__restrict__ block_powers,
+                                                     const double *__restrict__ ln_bounds,
+                                                     const double *__restrict__ ln_energy, TrackOut *__restrict__ outs)
+{
+    __shared__ uint32_t hh[kEbuBins];
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    __shared__ int lo_bin, hi_bin;
+    const TrackDesc &t = tracks[blockIdx.x];
+    TrackOut &o = outs[blockIdx.x];
+    const int C = t.ch;
+    const bool ln = gate_mode == 2;
+    const int nbins = ln ? kLnBins : kEbuBins;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
+    if (threadIdx.x == 0) { lo_bin = nbins; hi_bin = ln ? nbins : -1; }
+    __syncthreads();
+    const uint64_t n_s = t.n_hops >= 30 ? t.n_hops - 29 : 0;
+    const double bins = ln ? static_cast<double>(30 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
+                           : static_cast<double>(static_cast<uint64_t>(t.fs) * 30 / 10);
+    const double *H = hop_sums + t.hop_base + kPreHop * C;
+    double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
+    unsigned long long n_kept = 0;
+    for (uint64_t j = threadIdx.x; j < n_s; j += blockDim.x) {
+        double power = ln ? 0.0 : 1e-12;
+        for (int c = 0; c < C; c++) {
+            if (t.w[c] == 0.0f) continue;
+            double s = H[j * C + c];
+            for (int k = 1; k < 30; k++) s += H[(j + k) * C + c];
+            power += static_cast<double>(t.w[c]) * s;
+        }
+        power /= bins;
+        max_s = power > max_s ? power : max_s;
+        if (!ln) {
+            const double loud = -0.691 + 10.0 * log10(power);
+            if (loud >= -70.0) {
+                int b = static_cast<int>((loud - (-70.0)) * 100);
+                b = b < 0 ? 0 : (b > kEbuBins - 1 ? kEbuBins - 1 : b);
+                atomicAdd(&hh[b], 1u);
+                sum_kept += power;
+                n_kept++;
+            }
+        } else if (j % 10 == 0 && power >= ln_bounds[0]) {
+            int lo = 0, hi = kLnBins;
+            do {
+                const int mid = (lo + hi) / 2;
+                if (power >= ln_bounds[mid]) lo = mid; else hi = mid;
+            } while (hi - lo != 1);
+            atomicAdd(&hh[lo], 1u);
+        }
+    }
+    for (uint64_t jj = threadIdx.x; jj < t.n_blocks; jj += blockDim.x) {
+        const double p = block_powers[t.blk_base + jj];
+        max_m = p > max_m ? p : max_m;
+    }
+    max_s = block_reduce_max(max_s, shd);
+    max_m = block_reduce_max(max_m, shd);
+    // first bin of the range statistics and the mean power the relative gate derives from
+    int first = 0;
+    double rel_energy = 0.0;
+    bool any;
+    constexpr int kChunk = 32;  // bins per thread: 256 * 32 >= 8001
+    const int c0 = threadIdx.x * kChunk, c1 = c0 + kChunk < nbins ? c0 + kChunk : nbins;
+    if (!ln) {
+        const double sk = block_reduce_sum(sum_kept, shd);
+        const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
+        any = nk != 0;
+        if (any) {
+            double rt = sk / static_cast<double>(nk);
+            if (!rt) rt = 1e-12;
+            rel_energy = rt;
+            const double rel_thr = (-0.691 + 10.0 * log10(rt)) + (-20.0);
+            first = static_cast<int>((rel_thr - (-70.0)) * 100);
+            first = first < 0 ? 0 : (first > kEbuBins - 1 ? kEbuBins - 1 : first);
+        }
+    } else {
+        double gs = 0;
+        unsigned long long cnt = 0;
+        for (int i = c0; i < c1; i++) { cnt += hh[i]; gs += static_cast<double>(hh[i]) * ln_energy[i]; }
+        const double g1 = block_reduce_sum(gs, shd);
+        const unsigned long long a1 = block_reduce_sum_u64(cnt, shu);
+        any = a1 != 0;
+        if (any) {
+            rel_energy = g1 / static_cast<double>(a1);
+            const double integ = 0.01 * rel_energy;
+            if (integ >= ln_bounds[0]) {
+                int lo = 0, hi = kLnBins;
+                do {
+                    const int mid = (lo + hi) / 2;
+                    if (integ >= ln_bounds[mid]) lo = mid; else hi = mid;
+                } while (hi - lo != 1);
+                first = lo;
+                if (integ > ln_energy[first]) ++first;
+            }
+        }
+    }
+    if (any) {  // uniform across the workgroup
+        unsigned long long mine = 0;
+        for (int i = c0 > first ? c0 : first; i < c1; i++) mine += hh[i];
+        shu[threadIdx.x] = mine;
+        __syncthreads();
+        unsigned long long E = 0, total = 0;
+        for (int k = 0; k < 256; k++) {
+            if (k < static_cast<int>(threadIdx.x)) E += shu[k];
+            total += shu[k];
+        }
+        if (total) {
+            unsigned long long need_lo, need_hi;
+            if (!ln) {
+                need_lo = static_cast<unsigned long long>(10 * static_cast<double>(total) * 0.01 + 0.5);
+                need_hi = static_cast<unsigned long long>(95 * static_cast<double>(total) * 0.01 + 0.5);
+            } else {
+                need_lo = static_cast<unsigned long long>(static_cast<double>(total - 1) * 0.1 + 0.5);
+                need_hi = static_cast<unsigned long long>(static_cast<double>(total - 1) * 0.95 + 0.5);
+            }
+            for (int i = c0 > first ? c0 : first; i < c1; i++) {
+                const unsigned long long incl = E + hh[i];
+                if (!ln) {
+                    if (incl >= need_lo) atomicMin(&lo_bin, i);  // first bin whose running count reaches the 10 % count
+                    if (E < need_hi) atomicMax(&hi_bin, i);      // last bin with fewer than the 95 % count below it
+                } else {
+                    if (incl > need_lo) atomicMin(&lo_bin, i);
+                    if (incl > need_hi) atomicMin(&hi_bin, i);
+                }
+                E = incl;
+            }
+        }
+        __syncthreads();
+        any = total != 0;
+    }
+    if (threadIdx.x == 0) {
+        o.st_rel_energy = rel_energy;
+        o.max_m_power = max_m;
+        o.max_s_power = max_s;
+        o.n_shortterm = n_s;
+        o.lra_low_bin = any ? lo_bin : -1;
+        o.lra_high_bin = any ? hi_bin : -1;
+    }
+}
+
+void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
+                        const double *block_powers, const double *ln_bounds, const double *ln_energy, TrackOut *outs,
+                        hipStream_t st)
+{
+    if (!n_tracks) return;
+    hipLaunchKernelGGL(k_range_stats, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, hop_sums, block_powers, ln_bounds,
+                       ln_energy, outs);
+}
+
+// ---------------------------------------------------------------------------------------------
 // K3: true peak, generic f64.  One thread per input position; per-channel max via atomicMax on the
 // bit pattern (non-negative doubles order like unsigned integers).
 // ---------------------------------------------------------------------------------------------

@@ -90,6 +90,16 @@ typedef struct hr_result {
     double peak_per_ch[HR_MAX_CH]; /* linear true peak per channel (all channels, LFE too)    */
     int32_t status;            /* HR_OK or the error that made this track fail                */
     int32_t reserved;
+    /* The other numbers FFmpeg prints for a file (loudnorm JSON `input_lra`, `input_thresh` = rel_threshold_lufs;
+     * the ebur128 summary's "Loudness range" block), which src/analyzer.rs:102-106 leaves unread: SURVEY.md 8f.
+     * hr_analyze_batch fills them; the time-shard entry points (a 3 s window spans more than their 3-hop
+     * boundary exchange) set them to NaN. */
+    double loudness_range_lu;  /* LRA; 0 when no short-term block passes the gates                     */
+    double lra_low_lufs;       /* loudness at the 10 % point (NaN without a block)                     */
+    double lra_high_lufs;      /* loudness at the 95 % point                                           */
+    double lra_threshold_lufs; /* relative gate of the range: short-term mean - 20 LU                  */
+    double max_momentary_lufs; /* maximum 400 ms loudness (-INFINITY without a block)                  */
+    double max_shortterm_lufs; /* maximum 3 s loudness                                                 */
 } hr_result;
 
 /* Replaces check_ffmpeg() (src/analyzer.rs:348-354, called at src/cli.rs:30): number of usable

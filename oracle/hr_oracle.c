@@ -307,6 +307,122 @@ void hro_gate(const double *P, uint64_t n_blocks, int mode, hro_result *r, uint6
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Loudness range, maximum momentary / short-term loudness                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* power of the window of `len` hops that starts at hop j: the block formula of the mode */
+static double window_power(const double *H, uint64_t j, int len, int C, const float *w, uint32_t fs, int style)
+{
+    const double bins = style == 0 ? (double)((uint64_t)fs * (uint64_t)len / 10)
+                                   : (double)((uint64_t)len * (((uint64_t)fs + 5) / 10));
+    double power = style == 0 ? 1e-12 : 0.0;
+    for (int c = 0; c < C; c++) {
+        if (w[c] == 0.0f) continue;
+        double s = H[j * C + c];
+        for (int k = 1; k < len; k++) s += H[(j + k) * C + c];
+        power += (double)w[c] * s;
+    }
+    return power / bins;
+}
+
+void hro_range_stats(const double *H, uint64_t n_hops, int C, const float *w, uint32_t fs, int gate_mode,
+                     hro_range *o)
+{
+    const int style = gate_mode == HRO_GATE_LOUDNORM ? 1 : 0;
+    const uint64_t n_m = n_hops >= 4 ? n_hops - 3 : 0, n_s = n_hops >= 30 ? n_hops - 29 : 0;
+    double max_m = 0.0, max_s = 0.0;
+    o->lra = 0.0;
+    o->lra_low = o->lra_high = o->lra_threshold = NAN;
+    o->n_shortterm = n_s;
+    for (uint64_t j = 0; j < n_m; j++) {
+        const double p = window_power(H, j, 4, C, w, fs, style);
+        if (p > max_m) max_m = p;
+    }
+    if (style == 0) {
+        uint64_t *hist = (uint64_t *)calloc(EB_HIST_SIZE, sizeof(uint64_t));
+        double sum_kept = 0.0;
+        uint64_t n_kept = 0;
+        for (uint64_t j = 0; j < n_s; j++) {
+            const double p = window_power(H, j, 30, C, w, fs, 0);
+            if (p > max_s) max_s = p;
+            const double loud = LOUDNESS(p);
+            if (loud >= ABS_THRES) {
+                hist[clipi((int)((loud - ABS_THRES) * EB_HIST_GRAIN), 0, EB_HIST_SIZE - 1)]++;
+                sum_kept += p;
+                n_kept++;
+            }
+        }
+        if (n_kept) {
+            double rt = sum_kept / (double)n_kept;
+            if (!rt) rt = 1e-12;
+            const double rel_thr = LOUDNESS(rt) + (-20.0);
+            const int gp = clipi((int)((rel_thr - ABS_THRES) * EB_HIST_GRAIN), 0, EB_HIST_SIZE - 1);
+            uint64_t nb_powers = 0;
+            for (int i = gp; i < EB_HIST_SIZE; i++) nb_powers += hist[i];
+            o->lra_threshold = rel_thr;
+            if (nb_powers) {
+                uint64_t n = 0, nb_pow = (uint64_t)(10 * (double)nb_powers * 0.01 + 0.5);
+                for (int i = gp; i < EB_HIST_SIZE; i++) {
+                    n += hist[i];
+                    if (n >= nb_pow) { o->lra_low = (double)i / (double)EB_HIST_GRAIN + ABS_THRES; break; }
+                }
+                n = nb_powers;
+                nb_pow = (uint64_t)(95 * (double)nb_powers * 0.01 + 0.5);
+                for (int i = EB_HIST_SIZE - 1; i >= 0; i--) {
+                    n -= n < hist[i] ? n : hist[i];
+                    if (n < nb_pow) { o->lra_high = (double)i / (double)EB_HIST_GRAIN + ABS_THRES; break; }
+                }
+                o->lra = o->lra_high - o->lra_low;
+            }
+        }
+        free(hist);
+        o->max_momentary = n_m ? LOUDNESS(max_m) : -INFINITY;
+        o->max_shortterm = n_s ? LOUDNESS(max_s) : -INFINITY;
+    } else {
+        uint64_t hist[1000];
+        memset(hist, 0, sizeof hist);
+        ln_init();
+        for (uint64_t j = 0; j < n_s; j++) {
+            const double p = window_power(H, j, 30, C, w, fs, 1);
+            if (p > max_s) max_s = p;
+            if (j % 10 == 0 && p >= ln_bounds[0]) ++hist[ln_find_index(p)];
+        }
+        /* ff_ebur128_loudness_range (histogram form) */
+        uint64_t stl_size = 0;
+        double stl_power = 0.0;
+        for (int j = 0; j < 1000; ++j) { stl_size += hist[j]; stl_power += (double)hist[j] * ln_energies[j]; }
+        if (stl_size) {
+            stl_power /= (double)stl_size;
+            const double stl_integrated = 0.01 * stl_power; /* minus_twenty_decibels */
+            size_t index;
+            if (stl_integrated < ln_bounds[0]) index = 0;
+            else {
+                index = ln_find_index(stl_integrated);
+                if (stl_integrated > ln_energies[index]) ++index;
+            }
+            o->lra_threshold = 10.0 * (log(stl_integrated) / log(10.0)) - 0.691;
+            stl_size = 0;
+            for (size_t j = index; j < 1000; ++j) stl_size += hist[j];
+            if (stl_size) {
+                const uint64_t pl = (uint64_t)((double)(stl_size - 1) * 0.1 + 0.5);
+                const uint64_t ph = (uint64_t)((double)(stl_size - 1) * 0.95 + 0.5);
+                size_t j = index;
+                stl_size = 0;
+                while (stl_size <= pl) stl_size += hist[j++];
+                const double l_en = ln_energies[j - 1];
+                while (stl_size <= ph) stl_size += hist[j++];
+                const double h_en = ln_energies[j - 1];
+                o->lra_low = 10.0 * (log(l_en) / log(10.0)) - 0.691;
+                o->lra_high = 10.0 * (log(h_en) / log(10.0)) - 0.691;
+                o->lra = o->lra_high - o->lra_low;
+            }
+        }
+        o->max_momentary = n_m ? 10.0 * (log(max_m) / log(10.0)) - 0.691 : -INFINITY;
+        o->max_shortterm = n_s ? 10.0 * (log(max_s) / log(10.0)) - 0.691 : -INFINITY;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* libswresample filter bank                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 

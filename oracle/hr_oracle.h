@@ -100,6 +100,24 @@ uint64_t hro_block_powers(const double *H, uint64_t n_hops, int channels, const 
 /* Gating.  hist may be NULL; otherwise receives the histogram counts (8001 or 1000 entries). */
 void hro_gate(const double *P, uint64_t n_blocks, int mode, hro_result *r, uint64_t *hist);
 
+/* Loudness range and the maxima of the momentary (400 ms) and short-term (3 s) loudness.
+ *   gate modes EBUR128 / EXACT: f_ebur128.c -- a short-term power every hop once 3 s are filled,
+ *     (1e-12 + sum_c w_c * sum of 30 hops) / (3 fs); those >= -70 LUFS enter the i3000 histogram through
+ *     gate_update(.., LRA_GATE_THRES = -20); LRA = loudness of the bin holding the 95 % point minus that
+ *     of the 10 % point among the bins at or above the relative gate (the filter's own counting rule).
+ *   gate mode LOUDNORM: libavfilter/ebur128.c -- ff_ebur128_loudness_range on the 1000-bin histogram of
+ *     the short-term energies taken at 3 s and then every 1 s (what loudnorm prints as input_lra).
+ * lra is 0 when no short-term block passes; lra_low / lra_high / lra_threshold are NaN then.
+ * max_momentary / max_shortterm: LUFS, -inf without a block.  (Neither filter prints them; EBU Tech 3341
+ * defines them for a meter.  They use the mode's block power formula at every hop.) */
+typedef struct {
+    double lra, lra_low, lra_high, lra_threshold;
+    double max_momentary, max_shortterm;
+    uint64_t n_shortterm; /* short-term values produced (one per hop from the 30th) */
+} hro_range;
+void hro_range_stats(const double *H, uint64_t n_hops, int channels, const float *w, uint32_t fs,
+                     int gate_mode, hro_range *out);
+
 /* libswresample filter bank (filter_size 32, kaiser beta 9, exact_rational): returns phase_count
  * (0 if the rate pair is unsupported or needs no resampling) and the per-output input step
  * (dst_incr_div); taps must hold (phase_count+1)*32 doubles when not NULL. */

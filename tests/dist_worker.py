@@ -154,7 +154,8 @@ def mode_gpu(rank, world):
         # the same with the shard resident in HBM (device pointers, offset view for the tail)
         dev = torch.from_numpy(pcm[cuts[rank]:cuts[rank + 1]].copy()).cuda()
         got_d = sharded.analyze_stream_shard(dist, m, hr.TrackSpec(dev, fs), rank, world, 2)
-        assert got_d == got
+        # (the time-shard path reports the range statistics as NaN, and NaN != NaN)
+        assert all(got_d[k] == got[k] or (got_d[k] != got_d[k] and got[k] != got[k]) for k in got), (got_d, got)
         # a batch of independent tracks, split over the ranks
         tracks = [signals.seeded_noise(200 + i, fs * 3 + 100 * i, 2, -12.0 - i) for i in range(5)]
         lo, hi = sharded.partition_tracks(len(tracks), world, rank)

@@ -33,6 +33,11 @@ class Result(C.Structure):
                 ("n_gated", C.c_uint64), ("peak_per_ch", C.c_double * MAX_CH), ("status", C.c_int)]
 
 
+class Range(C.Structure):
+    _fields_ = [("lra", C.c_double), ("lra_low", C.c_double), ("lra_high", C.c_double), ("lra_threshold", C.c_double),
+                ("max_momentary", C.c_double), ("max_shortterm", C.c_double), ("n_shortterm", C.c_uint64)]
+
+
 class KCoef(C.Structure):
     _fields_ = [("pre_b", C.c_double * 3), ("pre_a", C.c_double * 3),
                 ("rlb_b", C.c_double * 3), ("rlb_a", C.c_double * 3)]
@@ -65,6 +70,8 @@ def lib():
         L.hro_block_powers.restype = C.c_uint64
         L.hro_gate.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int, C.POINTER(Result),
                                C.POINTER(C.c_uint64)]
+        L.hro_range_stats.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int, C.POINTER(C.c_float), C.c_uint32,
+                                      C.c_int, C.POINTER(Range)]
         L.hro_swr_bank.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.hro_swr_bank.restype = C.c_int
         L.hro_bs1770_taps.restype = C.POINTER(C.c_double)
@@ -152,6 +159,16 @@ def gate(P, mode=GATE_EBUR128, want_hist=False):
     if want_hist:
         d["hist"] = hist
     return d
+
+
+def range_stats(pcm, fs, gate_mode=GATE_EBUR128, weights=None, **kw):
+    """Loudness range and maximum momentary / short-term loudness of a track (hro_range_stats on its hop sums)."""
+    H = np.ascontiguousarray(hop_sums(pcm, fs, **kw))
+    nh, ch = H.shape
+    w = default_weights(ch) if weights is None else np.ascontiguousarray(weights, dtype=np.float32)
+    o = Range()
+    lib().hro_range_stats(_dp(H), nh, ch, w.ctypes.data_as(C.POINTER(C.c_float)), fs, gate_mode, C.byref(o))
+    return {f: getattr(o, f) for f, _ in Range._fields_}
 
 
 def swr_bank(in_rate, out_rate=192000):

@@ -64,6 +64,15 @@ def ebu3341_case(case, fs=48000):
     raise ValueError(case)
 
 
+def ebu3342_case(case, fs=48000):
+    """EBU Tech 3342 loudness-range test signals 1-4 (stereo 1 kHz sine, 20 s per level), synthesised from their
+    definitions.  Returns (pcm, expected LRA in LU); the tolerance of the document is +-1 LU."""
+    levels = {1: [-20.0, -30.0], 2: [-20.0, -15.0], 3: [-40.0, -20.0], 4: [-50.0, -35.0, -20.0, -35.0, -50.0]}[case]
+    n = np.arange(int(fs * 20.0 * len(levels)), dtype=np.float64)
+    amp = np.repeat([db(l) for l in levels], int(fs * 20.0))
+    return stereo(amp * np.sin(2.0 * np.pi * 1000.0 * n / fs)), {1: 10.0, 2: 5.0, 3: 20.0, 4: 15.0}[case]
+
+
 def seeded_noise(seed, frames, channels, dbfs=-20.0, kind="white"):
     rng = np.random.default_rng(seed)
     x = rng.uniform(-1.0, 1.0, size=(frames, channels))

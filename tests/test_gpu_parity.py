@@ -413,3 +413,47 @@ def test_split_wave_kernel_is_bit_identical(oracle, meters, fs, monkeypatch):
         assert got["integrated_lufs"] == base["integrated_lufs"] and got["peak_per_ch"] == base["peak_per_ch"]
     finally:
         m.close()
+
+
+# ---- loudness range, maximum momentary / short-term loudness ------------------------------
+
+def check_range(oracle, m, pcm, fs, gate, **kw):
+    ref = oracle.range_stats(pcm, fs, GATES[gate], **kw)
+    got = m.analyze(pcm, fs, **kw)
+    for k_got, k_ref in (("loudness_range_lu", "lra"), ("lra_low_lufs", "lra_low"), ("lra_high_lufs", "lra_high")):
+        if math.isnan(ref[k_ref]):
+            assert math.isnan(got[k_got]), (k_got, got, ref)
+        else:
+            assert abs(got[k_got] - ref[k_ref]) < 1e-9, (k_got, got, ref)  # bin positions: integers
+    for k_got, k_ref in (("lra_threshold_lufs", "lra_threshold"), ("max_momentary_lufs", "max_momentary"),
+                         ("max_shortterm_lufs", "max_shortterm")):
+        if math.isnan(ref[k_ref]) or math.isinf(ref[k_ref]):
+            assert got[k_got] == ref[k_ref] or (math.isnan(got[k_got]) and math.isnan(ref[k_ref])), (k_got, got, ref)
+        else:
+            assert abs(got[k_got] - ref[k_ref]) < 1e-6, (k_got, got, ref)
+    return got
+
+
+@pytest.mark.parametrize("gate", ["ebur128", "loudnorm"])
+@pytest.mark.parametrize("case", [1, 2, 3, 4])
+def test_ebu3342_loudness_range_on_gpu(oracle, meters, case, gate):
+    pcm, exp = signals.ebu3342_case(case)
+    got = check_range(oracle, meters(gate), pcm, 48000, gate)
+    assert abs(got["loudness_range_lu"] - exp) <= 1.0
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("gate", ["ebur128", "exact", "loudnorm"])
+def test_range_stats_noise_multichannel_and_short(oracle, meters, gate, engine):
+    m = meters(gate, "swr192k", engine)
+    fs = 44100
+    rng = np.random.default_rng(5)
+    x = signals.seeded_noise(61, fs * 42, 2, -14.0)
+    env = np.repeat(10.0 ** (rng.uniform(-30.0, 0.0, size=42) / 20.0), fs).astype(np.float32)  # a new level every second
+    check_range(oracle, m, x * env[:, None], fs, gate)
+    x6 = signals.seeded_noise(62, 48000 * 8, 6, -20.0)
+    x6[: 48000 * 3] *= 0.05
+    check_range(oracle, m, x6, 48000, gate)
+    check_range(oracle, m, x[: fs * 2], fs, gate)            # momentary blocks, no 3 s window
+    check_range(oracle, m, x[: fs // 4], fs, gate)           # no block at all
+    check_range(oracle, m, np.zeros((fs * 4, 2), np.float32), fs, gate)  # silence

@@ -225,3 +225,30 @@ def test_oracle_reproduces_golden_vectors(oracle, idx):
         li = float.fromhex(exp["integrated_lufs"])
         assert r["integrated_lufs"] == li or abs(r["integrated_lufs"] - li) < 1e-10
         assert [float.hex(float(x)) for x in r["peak_per_ch"]] == exp["peak_per_ch"]
+
+
+# ---- loudness range, maximum momentary / short-term loudness ------------------------------
+
+@pytest.mark.parametrize("gate", [0, 2])  # ebur128 / loudnorm
+@pytest.mark.parametrize("case", [1, 2, 3, 4])
+def test_ebu3342_loudness_range_cases(oracle, case, gate):
+    pcm, exp = signals.ebu3342_case(case)
+    r = oracle.range_stats(pcm, 48000, gate)
+    assert abs(r["lra"] - exp) <= 1.0, r
+    assert r["lra_low"] < r["lra_high"]
+    assert r["n_shortterm"] == len(pcm) // 4800 - 29
+
+
+def test_range_stats_of_steady_tone_and_short_input(oracle):
+    fs = 48000
+    x = signals.stereo(signals.sine(fs, 1000.0, -23.0, 10.0))
+    for gate in (oracle.GATE_EBUR128, oracle.GATE_LOUDNORM):
+        r = oracle.range_stats(x, fs, gate)
+        assert r["lra"] <= 0.11                              # one histogram bin at most
+        assert abs(r["max_momentary"] - (-23.0)) < 0.05      # a steady tone: M = S = I = -23 LUFS
+        assert abs(r["max_shortterm"] - (-23.0)) < 0.05
+        short = oracle.range_stats(x[: fs * 2], fs, gate)  # 2 s: momentary blocks but no 3 s window yet
+        assert short["n_shortterm"] == 0 and short["lra"] == 0.0 and np.isnan(short["lra_low"])
+        assert short["max_shortterm"] == -np.inf and abs(short["max_momentary"] + 23.0) < 0.05
+        silent = oracle.range_stats(np.zeros((fs * 5, 2), np.float32), fs, gate)
+        assert silent["lra"] == 0.0 and np.isnan(silent["lra_threshold"])
