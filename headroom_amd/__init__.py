@@ -72,7 +72,7 @@ class HrPcmInfo(C.Structure):
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
-           "hr_report_csv_header", "hr_report_csv_row"]
+           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain"]
 
 _lib = None
 
@@ -114,6 +114,7 @@ def lib():
     L.hr_pcm_load_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(HrTrack), C.POINTER(C.c_float)]
     L.hr_report_csv_header.argtypes = [C.c_char_p, C.c_size_t]
     L.hr_report_csv_row.argtypes = [C.c_char_p, C.POINTER(HrAnalysis), C.c_char_p, C.c_size_t]
+    L.hr_apply_gain.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     L.hr_strerror.argtypes = [C.c_int]
@@ -245,6 +246,21 @@ class Meter:
                                        P.ctypes.data_as(C.POINTER(C.c_double)), nh, C.byref(n_h), C.byref(n_b)),
                "hr_block_energies")
         return H[:n_h.value], P[:n_b.value]
+
+    def apply_gain(self, spec, gain_db, big_endian=False, out_device_ptr=None):
+        """hr_apply_gain: packed 24-bit PCM of the track times 10^(gain_db/20).  Host track: returns (uint8 array,
+        clipped); device track: writes frames*channels*3 bytes at out_device_ptr and returns (None, clipped)."""
+        import numpy as np
+        clipped = C.c_uint64(0)
+        if out_device_ptr is not None:
+            _check(lib().hr_apply_gain(self._h, C.byref(spec.c), gain_db, int(big_endian), C.c_void_p(int(out_device_ptr)),
+                                       C.byref(clipped)), "hr_apply_gain")
+            return None, int(clipped.value)
+        nbytes = int(spec.c.frames) * spec.channels * 3
+        out = np.zeros(max(nbytes, 1), dtype=np.uint8)
+        _check(lib().hr_apply_gain(self._h, C.byref(spec.c), gain_db, int(big_endian), out.ctypes.data_as(C.c_void_p),
+                                   C.byref(clipped)), "hr_apply_gain")
+        return out[:nbytes], int(clipped.value)
 
     def synth_fill(self, device_ptr, seed, sample_rate, channels, frames):
         _check(lib().hr_synth_fill(self._h, C.c_void_p(int(device_ptr)), seed, sample_rate, channels, frames), "hr_synth_fill")

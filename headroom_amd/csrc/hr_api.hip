@@ -77,7 +77,7 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
 
     // workspace (grow-only)
-    DevBuf widened, parents_d, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, parents_d, counters, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
@@ -682,7 +682,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
-                      &ctx->widened, &ctx->parents_d, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->widened, &ctx->parents_d, &ctx->counters, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -1050,6 +1050,41 @@ int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *tr
         for (int c = 0; c < HR_MAX_CH; c++) red.peak_per_ch[c] = std::max(red.peak_per_ch[c], part[r].peak_per_ch[c]);
     }
     return hr_shard_finish(ctxs[0], &red, track->channels, out);
+}
+
+int hr_apply_gain(hr_ctx *ctx, const hr_track *track, double gain_db, int out_big_endian, void *out, uint64_t *clipped)
+{
+    if (!ctx || !track || (track->frames && (!track->pcm || !out)) || !std::isfinite(gain_db)) return HR_ERR_INVALID;
+    if (track->channels < 1 || track->channels > HR_MAX_CH || fmt_bytes(track->fmt) == 0) return HR_ERR_FORMAT;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->stream;
+    const uint64_t n = track->frames * track->channels;
+    const size_t in_bytes = n * fmt_bytes(track->fmt), out_bytes = n * 3;
+    const bool on_dev = (track->flags & HR_TRACK_DEVICE_PCM) != 0;
+    if (on_dev && (reinterpret_cast<uintptr_t>(out) & 3)) return HR_ERR_INVALID;
+    const void *src = track->pcm;
+    void *dst = out;
+    const size_t in_pad = (in_bytes + 255) / 256 * 256;
+    if (!ctx->counters.ensure(256)) return HR_ERR_OOM;
+    unsigned long long *cnt = ctx->counters.as<unsigned long long>();
+    HIPCHK(hipMemsetAsync(cnt, 0, sizeof *cnt, st));
+    if (!on_dev) {
+        if (!ctx->stage.ensure(in_pad + out_bytes + 256)) return HR_ERR_OOM;
+        if (in_bytes) HIPCHK(hipMemcpyAsync(ctx->stage.p, track->pcm, in_bytes, hipMemcpyHostToDevice, st));
+        src = ctx->stage.p;
+        dst = static_cast<char *>(ctx->stage.p) + in_pad;
+    }
+    // volume=XdB: the expression evaluator turns "XdB" into 10^(X/20) (double); the float path multiplies by (float) of it
+    const float vol = static_cast<float>(std::pow(10.0, gain_db / 20.0));
+    launch_apply_gain(track->fmt, out_big_endian != 0, src, dst, n, vol, cnt, st);
+    HIPCHK(hipGetLastError());
+    unsigned long long c = 0;
+    if (!on_dev && out_bytes) HIPCHK(hipMemcpyAsync(out, dst, out_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&c, cnt, sizeof c, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (clipped) *clipped = c;
+    return HR_OK;
 }
 
 int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_rate, uint32_t channels, uint64_t frames)

@@ -47,6 +47,11 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
                        HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int tp_class, int dbg,
                        hipStream_t st);
 
+// hr_gain.hip: interleaved PCM of format fmt times vol (f32) -> packed s24 (dst dword aligned); *clipped += samples
+// that saturated
+void launch_apply_gain(int fmt, bool big_endian, const void *src, void *dst, uint64_t n_samples, float vol,
+                       unsigned long long *clipped, hipStream_t st);
+
 // hr_synth.hip
 struct SynthPar {
     float a_noise, a_sine, burst;

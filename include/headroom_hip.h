@@ -233,6 +233,14 @@ typedef struct hr_analysis { /* AudioAnalysis minus the path strings, src/analyz
 int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
                      const hr_tp_target *mode, hr_analysis *out);
 
+/* Lossless gain for PCM files, replacing `ffmpeg -i in -af volume={gain}dB -c:a pcm_s24le|pcm_s24be out`
+ * (apply_gain_ffmpeg, src/processor.rs:53-87; WAV -> pcm_s24le, AIFF -> pcm_s24be): every sample of `track` times
+ * 10^(gain_db/20) in the arithmetic of that FFmpeg chain (f32 volume filter, round-to-nearest-even to 32 bits,
+ * saturating, upper three bytes kept), written to `out` as packed 24-bit (frames * channels * 3 bytes; big endian
+ * when out_big_endian != 0).  `out` is a device pointer when the track carries HR_TRACK_DEVICE_PCM, else a host
+ * pointer.  *clipped (may be NULL) receives the number of samples that saturated. */
+int hr_apply_gain(hr_ctx *ctx, const hr_track *track, double gain_db, int out_big_endian, void *out, uint64_t *clipped);
+
 /* One line of the CSV report, src/report.rs:29-59: the header record, and the record of one analysed file
  * (labels: GainMethod::format_label / method_label, src/analyzer.rs:80-100; numbers with one decimal, headroom and
  * gain signed; fields quoted as the csv crate does by default).  Return the length written (without the NUL), or

@@ -307,6 +307,46 @@ void hro_gate(const double *P, uint64_t n_blocks, int mode, hro_result *r, uint6
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* Lossless gain (volume filter + pcm_s24 encoder)                                            */
+/* ------------------------------------------------------------------------------------------ */
+
+static float sample_as_flt(const void *pcm, int fmt, uint64_t idx)
+{
+    switch (fmt) { /* libswresample/audioconvert.c CONV_FUNC(..FLT..) */
+    case HRO_FMT_F32: return ((const float *)pcm)[idx];
+    case HRO_FMT_S16: return (float)((const int16_t *)pcm)[idx] * (1.0f / (1 << 15));
+    case HRO_FMT_S24: { /* the pcm_s24le decoder hands over s32 = v << 8 */
+        const uint8_t *p = (const uint8_t *)pcm + 3 * idx;
+        const int32_t v = (int32_t)((uint32_t)p[0] << 8 | (uint32_t)p[1] << 16 | (uint32_t)p[2] << 24);
+        return (float)v * (1.0f / (1U << 31));
+    }
+    case HRO_FMT_S32: return (float)((const int32_t *)pcm)[idx] * (1.0f / (1U << 31));
+    default: return (float)((const double *)pcm)[idx];
+    }
+}
+
+uint64_t hro_apply_gain(const hro_track *t, double gain_db, int big_endian, uint8_t *out)
+{
+    const float vol = (float)pow(10.0, gain_db / 20.0);
+    const uint64_t n = t->frames * t->channels;
+    uint64_t clipped = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        const float y = sample_as_flt(t->pcm, t->fmt, i) * vol; /* vector_fmul_scalar */
+        const long long q = llrintf(y * (float)(1U << 31));
+        int32_t s;
+        if (y != y) { s = INT32_MIN; clipped++; } /* x86 llrintf(NaN) = LLONG_MIN */
+        else if (q > INT32_MAX) { s = INT32_MAX; clipped++; }
+        else if (q < INT32_MIN) { s = INT32_MIN; clipped++; }
+        else s = (int32_t)q;
+        const uint32_t u = (uint32_t)s;
+        out[3 * i + (big_endian ? 2 : 0)] = (uint8_t)(u >> 8);
+        out[3 * i + 1] = (uint8_t)(u >> 16);
+        out[3 * i + (big_endian ? 0 : 2)] = (uint8_t)(u >> 24);
+    }
+    return clipped;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* Loudness range, maximum momentary / short-term loudness                                    */
 /* ------------------------------------------------------------------------------------------ */
 

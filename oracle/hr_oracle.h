@@ -141,6 +141,12 @@ int hro_ebur128_literal(const hro_track *t, hro_result *r, double *block_powers,
  * resampled signal. */
 int hro_loudnorm_measure(const hro_track *t, hro_result *r);
 
+/* Lossless gain as `ffmpeg -af volume={g}dB -c:a pcm_s24le|pcm_s24be` computes it (src/processor.rs:53-87):
+ * sample -> f32 (libswresample audioconvert), times (float)10^(g/20) in f32 (af_volume.c, precision float),
+ * av_clipl_int32(llrintf(y * 2^31)), upper three bytes written.  out: frames*channels*3 bytes.  Returns the
+ * number of samples that saturated. */
+uint64_t hro_apply_gain(const hro_track *t, double gain_db, int big_endian, uint8_t *out);
+
 /* Deterministic synthetic PCM (f32 interleaved), SURVEY.md 8(d): noise + sine + quiet intro/outro +
  * inter-sample-peak bursts.  Same generator as the device kernel hr_synth_fill. */
 void hro_synth_track(uint64_t seed, uint32_t fs, int channels, uint64_t frames, float *out);

@@ -72,6 +72,8 @@ def lib():
                                C.POINTER(C.c_uint64)]
         L.hro_range_stats.argtypes = [C.POINTER(C.c_double), C.c_uint64, C.c_int, C.POINTER(C.c_float), C.c_uint32,
                                       C.c_int, C.POINTER(Range)]
+        L.hro_apply_gain.argtypes = [C.POINTER(Track), C.c_double, C.c_int, C.POINTER(C.c_uint8)]
+        L.hro_apply_gain.restype = C.c_uint64
         L.hro_swr_bank.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(C.c_int), C.POINTER(C.c_double)]
         L.hro_swr_bank.restype = C.c_int
         L.hro_bs1770_taps.restype = C.POINTER(C.c_double)
@@ -169,6 +171,14 @@ def range_stats(pcm, fs, gate_mode=GATE_EBUR128, weights=None, **kw):
     o = Range()
     lib().hro_range_stats(_dp(H), nh, ch, w.ctypes.data_as(C.POINTER(C.c_float)), fs, gate_mode, C.byref(o))
     return {f: getattr(o, f) for f, _ in Range._fields_}
+
+
+def apply_gain(pcm, fs, gain_db, big_endian=False, **kw):
+    """hro_apply_gain: (packed s24 bytes as uint8 array, number of saturated samples)."""
+    t, keep = make_track(pcm, fs, **kw)
+    out = np.zeros(t.frames * t.channels * 3, dtype=np.uint8)
+    clipped = lib().hro_apply_gain(C.byref(t), gain_db, int(big_endian), out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out, int(clipped)
 
 
 def swr_bank(in_rate, out_rate=192000):

@@ -252,3 +252,21 @@ def test_range_stats_of_steady_tone_and_short_input(oracle):
         assert short["max_shortterm"] == -np.inf and abs(short["max_momentary"] + 23.0) < 0.05
         silent = oracle.range_stats(np.zeros((fs * 5, 2), np.float32), fs, gate)
         assert silent["lra"] == 0.0 and np.isnan(silent["lra_threshold"])
+
+
+# ---- lossless gain ------------------------------------------------------------------------
+
+def test_apply_gain_known_answers(oracle):
+    # +6.0206 dB is a factor 2 within f32 rounding: 0.25 -> 2^22, -0.125 -> -2^21 in 24-bit units (+-1 for the rounding)
+    x = np.array([[0.25, -0.125]], dtype=np.float32)
+    out, clipped = oracle.apply_gain(x, 48000, 20.0 * math.log10(2.0))
+    v = [int.from_bytes(bytes(out[3 * i: 3 * i + 3]), "little", signed=True) for i in range(2)]
+    assert clipped == 0 and abs(v[0] - (1 << 22)) <= 1 and abs(v[1] + (1 << 21)) <= 1
+    # unity gain keeps 24-bit PCM bit for bit, in both byte orders
+    raw = signals.to_s24_bytes(signals.seeded_noise(3, 1000, 2, -2.0).astype(np.float64))
+    le, _ = oracle.apply_gain(raw, 48000, 0.0, channels=2, fmt=oracle.FMT_S24)
+    be, _ = oracle.apply_gain(raw, 48000, 0.0, True, channels=2, fmt=oracle.FMT_S24)
+    assert np.array_equal(le, raw) and np.array_equal(be.reshape(-1, 3)[:, ::-1].reshape(-1), raw)
+    # saturation: +1.0 full scale cannot be represented, -1.0 can
+    out, clipped = oracle.apply_gain(np.array([[1.0, -1.0]], dtype=np.float32), 48000, 0.0)
+    assert clipped == 1 and bytes(out) == b"\xff\xff\x7f\x00\x00\x80"
