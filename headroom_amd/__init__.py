@@ -72,7 +72,7 @@ class HrPcmInfo(C.Structure):
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
-           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain"]
+           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass"]
 
 _lib = None
 
@@ -114,6 +114,7 @@ def lib():
     L.hr_pcm_load_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(HrTrack), C.POINTER(C.c_float)]
     L.hr_report_csv_header.argtypes = [C.c_char_p, C.c_size_t]
     L.hr_report_csv_row.argtypes = [C.c_char_p, C.POINTER(HrAnalysis), C.c_char_p, C.c_size_t]
+    L.hr_loudnorm_first_pass.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_size_t, C.POINTER(HrResult)]
     L.hr_apply_gain.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -232,6 +233,14 @@ class Meter:
         out = (HrResult * max(n, 1))()
         _check(lib().hr_analyze_batch(self._h, arr, n, out), "hr_analyze_batch")
         return [_result_dict(out[i], specs[i].channels or 0) for i in range(n)]
+
+    def loudnorm_first_pass(self, specs):
+        """hr_loudnorm_first_pass: what `ffmpeg -af loudnorm=print_format=json` measures (src/analyzer.rs:253-267)."""
+        n = len(specs)
+        arr = (HrTrack * max(n, 1))(*[s.c for s in specs])
+        res = (HrResult * max(n, 1))()
+        _check(lib().hr_loudnorm_first_pass(self._h, arr, n, res), "hr_loudnorm_first_pass")
+        return [_result_dict(res[i], specs[i].channels) for i in range(n)]
 
     def analyze(self, pcm, sample_rate, **kw):
         return self.analyze_batch([TrackSpec(pcm, sample_rate, **kw)])[0]

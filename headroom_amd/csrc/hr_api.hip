@@ -74,10 +74,10 @@ struct hr_ctx {
     std::vector<uint32_t> rate_fs;
     std::vector<RateDev> rates_h;
     std::vector<void *> rate_allocs;
-    DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps;
+    DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps, unit_tap;
 
     // workspace (grow-only)
-    DevBuf widened, parents_d, counters, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, resampled, parents_d, counters, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
@@ -670,6 +670,9 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     if (!rc) rc = upload(ctx->ln_energy, loudnorm_bin_energy().data(), kLnBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_bounds, loudnorm_bin_bounds().data(), (kLnBins + 1) * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->bs_taps, bs1770_taps(), 48 * sizeof(double), ctx->stream);
+    double unit[kSwrTaps] = {0};
+    unit[15] = 1.0;  // the centre tap: a one-phase "bank" that passes 192 kHz input through
+    if (!rc) rc = upload(ctx->unit_tap, unit, sizeof unit, ctx->stream);
     if (!rc && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = HR_ERR_HIP;
     if (rc) { hr_destroy(ctx); return rc; }
     *out = ctx;
@@ -681,8 +684,8 @@ void hr_destroy(hr_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->tracks_d,
-                      &ctx->widened, &ctx->parents_d, &ctx->counters, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->unit_tap, &ctx->tracks_d,
+                      &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -1050,6 +1053,100 @@ int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *tr
         for (int c = 0; c < HR_MAX_CH; c++) red.peak_per_ch[c] = std::max(red.peak_per_ch[c], part[r].peak_per_ch[c]);
     }
     return hr_shard_finish(ctxs[0], &red, track->channels, out);
+}
+
+int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out)
+{
+    if (!ctx || (n && (!tracks || !out))) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    ctx->last_total_ms = ctx->last_main_ms = 0;
+    hipStream_t st = ctx->stream;
+    // libavfilter/ebur128.c channel map by index (af_loudnorm sets no layout-specific map): L R C LFE Ls Rs
+    static const float wln[HR_MAX_CH + 1][HR_MAX_CH] = {
+        {0}, {1}, {1, 1}, {1, 1, 1}, {1, 1, 1.41f, 1.41f}, {1, 1, 1, 1.41f, 1.41f},
+        {1, 1, 1, 0, 1.41f, 1.41f}, {1, 1, 1, 0, 1.41f, 1.41f, 0}, {1, 1, 1, 0, 1.41f, 1.41f, 0, 0}};
+    const hr_config saved = ctx->cfg;
+    ctx->cfg.gate_mode = HR_GATE_LOUDNORM;
+    ctx->cfg.tp_mode = HR_TP_SAMPLE;
+    const double ninf = -std::numeric_limits<double>::infinity(), nan = std::numeric_limits<double>::quiet_NaN();
+    const size_t limit = 8ull << 30;  // resampled f64 PCM per group
+    int fatal = HR_OK;
+    size_t i = 0;
+    while (i < n && !fatal) {
+        // tracks [i, j): as many as fit the resampled-PCM budget (at least one)
+        std::vector<hr_track> pseudo;
+        std::vector<size_t> src_idx, off;
+        size_t need = 0, j = i;
+        for (; j < n; j++) {
+            const hr_track &t = tracks[j];
+            std::memset(&out[j], 0, sizeof out[j]);
+            out[j].integrated_lufs = out[j].true_peak_dbtp = out[j].rel_threshold_lufs = ninf;
+            out[j].loudness_range_lu = out[j].lra_low_lufs = out[j].lra_high_lufs = out[j].lra_threshold_lufs =
+                out[j].max_momentary_lufs = out[j].max_shortterm_lufs = nan;
+            int v = HR_OK;
+            const RateTables *rt = nullptr;
+            if (t.channels < 1 || t.channels > HR_MAX_CH || fmt_bytes(t.fmt) == 0) v = HR_ERR_FORMAT;
+            else if (t.sample_rate < 10 || !(rt = rate_tables(t.sample_rate)) || rt->swr_phases < 0 ||
+                     (rt->swr_phases == 0 && t.sample_rate != 192000)) v = HR_ERR_RATE;
+            else if (t.frames && !t.pcm) v = HR_ERR_INVALID;
+            if (v) { out[j].status = v; continue; }
+            uint64_t m = t.frames;  // frames at 192 kHz
+            if (rt->swr_phases > 0)
+                m = t.frames >= kSwrTaps + 1 ? (t.frames * rt->swr_phases + rt->swr_step - 1) / rt->swr_step : 0;
+            const size_t bytes = (m * t.channels * sizeof(double) + 255) / 256 * 256;
+            if (!pseudo.empty() && need + bytes > limit) break;
+            hr_track p = t;
+            p.frames = m;
+            p.sample_rate = 192000;
+            p.fmt = HR_FMT_F64;
+            p.flags = HR_TRACK_DEVICE_PCM;
+            if (!p.ch_weight) p.ch_weight = wln[t.channels];
+            pseudo.push_back(p);
+            src_idx.push_back(j);
+            off.push_back(need);
+            need += bytes;
+        }
+        if (!pseudo.empty()) {
+            int rc = ctx->resampled.ensure(need + 256) ? HR_OK : HR_ERR_OOM;
+            for (size_t k = 0; k < pseudo.size() && !rc; k++) {
+                const hr_track &t = tracks[src_idx[k]];
+                double *dst = reinterpret_cast<double *>(static_cast<char *>(ctx->resampled.p) + off[k]);
+                pseudo[k].pcm = dst;
+                const size_t in_bytes = t.frames * t.channels * fmt_bytes(t.fmt);
+                if (!pseudo[k].frames || !in_bytes) continue;
+                const void *src = t.pcm;
+                if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
+                    if (!ctx->stage.ensure(in_bytes + 256)) { rc = HR_ERR_OOM; break; }
+                    if (hipMemcpyAsync(ctx->stage.p, t.pcm, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = HR_ERR_HIP; break; }
+                    // (a grown staging buffer is a new allocation: hipFree of the old one waits for the work that reads it)
+                    src = ctx->stage.p;
+                }
+                const int ri = rate_index(ctx, t.sample_rate);
+                if (ri < 0) { rc = ri; break; }
+                const RateDev &rd = ctx->rates_h[ri];
+                if (rd.swr_phases > 0)
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, rd.swr_phases, rd.swr_step, rd.swr_taps, dst, st);
+                else  // 192 kHz input: the resampler passes it through; the f64 copy keeps one code path
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, ctx->unit_tap.as<double>(), dst, st);
+            }
+            if (!rc && hipGetLastError() != hipSuccess) rc = HR_ERR_HIP;
+            std::vector<hr_result> res(pseudo.size());
+            if (!rc) {
+                std::vector<size_t> idx(pseudo.size());
+                for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
+                rc = analyze_group(ctx, pseudo.data(), idx, res.data());
+            }
+            for (size_t k = 0; k < pseudo.size(); k++) {
+                if (rc) out[src_idx[k]].status = rc;
+                else out[src_idx[k]] = res[k];
+            }
+            if (rc == HR_ERR_HIP) fatal = rc;
+        }
+        i = j;
+    }
+    ctx->cfg = saved;
+    return fatal;
 }
 
 int hr_apply_gain(hr_ctx *ctx, const hr_track *track, double gain_db, int out_big_endian, void *out, uint64_t *clipped)

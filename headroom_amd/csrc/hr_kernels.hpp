@@ -24,6 +24,9 @@ void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
                         const double *block_powers, const double *ln_bounds, const double *ln_energy, TrackOut *outs,
                         hipStream_t st);
+// libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases/step) interleaved f64 frames
+void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, const double *taps,
+                         double *dst, hipStream_t st);
 // hop sums of the stereo planes of a split track -> the track's own (hop, channel) slots; one workgroup per parent
 void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
 // tp_kind: 0 swr192k, 1 bs1770, 2 sample peak; every item covers `span` (multiple of 256) positions, or item.pad

@@ -634,6 +634,49 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
     }
 }
 
+// The whole 192 kHz stream instead of its maximum: what the `aresample` in front of af_loudnorm produces (libswresample
+// defaults, f64; start reflected x[-k] = x[k], and, unlike f_ebur128's private resampler, flushed at the end with
+// the reflection x[N+j] = x[N-1-j]).  One thread per input position writes the outputs n with floor(n*step/P) == pos.
+template <int FMT>
+__global__ void __launch_bounds__(256) k_resample_swr(const void *__restrict__ src, int64_t N, int C, int P, int step,
+                                                      const double *__restrict__ taps, double *__restrict__ dst)
+{
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
+    for (int64_t pos = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; pos < N; pos += stride) {
+        const int64_t n_lo = (pos * P + step - 1) / step;
+        const int64_t n_hi = ((pos + 1) * P + step - 1) / step;
+        for (int c = 0; c < C; c++) {
+            double x[kSwrTaps];
+#pragma unroll
+            for (int i = 0; i < kSwrTaps; i++) {
+                int64_t k = pos - 15 + i;
+                if (k < 0) k = -k;
+                if (k >= N) k = 2 * N - 1 - k;
+                x[i] = (k < 0 || k >= N) ? 0.0 : ld_sample<FMT>(src, static_cast<uint64_t>(k) * C + c);
+            }
+            for (int64_t n = n_lo; n < n_hi; n++) {
+                const int ph = static_cast<int>(n * step - pos * P);
+                const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
+                double val = 0.0;
+#pragma unroll
+                for (int i = 0; i < kSwrTaps; i++) val = fma(x[i], f[i], val);
+                dst[n * C + c] = val;
+            }
+        }
+    }
+}
+
+void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, const double *taps,
+                         double *dst, hipStream_t st)
+{
+    if (!frames) return;
+    uint64_t blocks = (frames + 255) / 256;
+    if (blocks > 256 * 64) blocks = 256 * 64;
+#define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, taps, dst); break;
+    switch (fmt) { HR_RS_CASE(0) HR_RS_CASE(1) HR_RS_CASE(2) HR_RS_CASE(3) default: HR_RS_CASE(4) }
+#undef HR_RS_CASE
+}
+
 template <int FMT>
 __global__ void __launch_bounds__(256) k_true_peak_bs1770(const TrackDesc *__restrict__ tracks,
                                                           const double *__restrict__ taps /*[4][12]*/,

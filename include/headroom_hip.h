@@ -233,6 +233,16 @@ typedef struct hr_analysis { /* AudioAnalysis minus the path strings, src/analyz
 int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
                      const hr_tp_target *mode, hr_analysis *out);
 
+/* The measurement the reference literally asks FFmpeg for: the first pass of `-af loudnorm=print_format=json`
+ * (src/analyzer.rs:253-267; `input_i`, `input_tp`, `input_lra`, `input_thresh` of its JSON).  af_loudnorm negotiates
+ * 192 kHz f64 input, so every track is first resampled to 192 kHz with libswresample's defaults (flushed at the
+ * end) and then measured AT 192 kHz: K-weighting for fs = 192000, libavfilter/ebur128.c's 1000 x 0.1 LU histogram
+ * gating with its channel map by index (L R C LFE Ls Rs: LFE and channels beyond six unweighted), and the sample
+ * peak of the resampled signal as `input_tp`.  The context's gate / true-peak modes are not used.  Same batch
+ * semantics as hr_analyze_batch.  Rates above 192 kHz: HR_ERR_RATE.  This is a parity mode (the resampled stream is
+ * 4-4.35x the input, in f64, and takes the generic kernels); hr_analyze_batch is the fast path. */
+int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out);
+
 /* Lossless gain for PCM files, replacing `ffmpeg -i in -af volume={gain}dB -c:a pcm_s24le|pcm_s24be out`
  * (apply_gain_ffmpeg, src/processor.rs:53-87; WAV -> pcm_s24le, AIFF -> pcm_s24be): every sample of `track` times
  * 10^(gain_db/20) in the arithmetic of that FFmpeg chain (f32 volume filter, round-to-nearest-even to 32 bits,

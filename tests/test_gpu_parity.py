@@ -457,3 +457,36 @@ def test_range_stats_noise_multichannel_and_short(oracle, meters, gate, engine):
     check_range(oracle, m, x[: fs * 2], fs, gate)            # momentary blocks, no 3 s window
     check_range(oracle, m, x[: fs // 4], fs, gate)           # no block at all
     check_range(oracle, m, np.zeros((fs * 4, 2), np.float32), fs, gate)  # silence
+
+
+# ---- the literal af_loudnorm first pass (what src/analyzer.rs:261 asks ffmpeg for) -------------------------------
+
+def test_loudnorm_first_pass_matches_oracle(oracle, meters):
+    m = meters()
+    cases = []
+    for fs in (44100, 48000, 96000, 192000):
+        x = signals.seeded_noise(300 + fs, int(fs * 4.3) + 17, 2, -15.0)
+        x[: fs] *= 0.01
+        cases.append((x, fs, {}))
+    cases.append((signals.to_s16(signals.seeded_noise(41, 44100 * 3, 1, -8.0)), 44100, {}))
+    x6 = signals.seeded_noise(42, 48000 * 3 + 5, 6, -12.0)
+    cases.append((x6, 48000, {}))
+    cases.append((signals.seeded_noise(43, 20, 2, -12.0), 48000, {}))          # shorter than the resampler's window
+    cases.append((np.zeros((48000, 2), np.float32), 48000, {}))                 # silence
+    got = m.loudnorm_first_pass([hr.TrackSpec(p, fs, **kw) for p, fs, kw in cases])
+    for (p, fs, kw), g in zip(cases, got):
+        ref = oracle.loudnorm_measure(p, fs, **kw)
+        assert g["status"] == 0 and g["n_blocks"] == ref["n_blocks"], (fs, g, ref)
+        assert g["peak_per_ch"] == ref["peak_per_ch"], (fs, g, ref)             # same f64 FMA chain: bit-identical
+        assert g["true_peak_dbtp"] == ref["true_peak_dbtp"]
+        if math.isfinite(ref["integrated_lufs"]):
+            # the oracle runs libebur128's 4th-order direct form II, the GPU two biquads from zero state per hop:
+            # block energies agree to ~1e-12, the 0.1 LU histogram makes the result a step function of them
+            assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6, (fs, g, ref)
+        else:
+            assert g["integrated_lufs"] == ref["integrated_lufs"]
+    # the context's own modes are untouched by the call
+    pcm, fs, _ = cases[0]
+    check_against_oracle(oracle, m, pcm, fs)
+    bad = m.loudnorm_first_pass([hr.TrackSpec(signals.seeded_noise(1, 1000, 2), 384000)])
+    assert bad[0]["status"] == hr.ERR_RATE
