@@ -739,22 +739,27 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 // 148 KiB workgroup per CU; deeper piece rings change nothing.  It is therefore opt-in (HR_FUSED_SPLIT=1) and kept
 // as the vehicle for per-role timing: wave_map bit 0 = pairing of waves (0: w / w+4, 1: 2p / 2p+1), bit 1 = the
 // K-weighting waves only move data, bit 2 = the true-peak waves only move data (results are wrong with bits 1, 2).
-constexpr int kSplitLds = 16 * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
+constexpr int split_lds(int pairs, int ring) { return pairs * ring * kPieceLds + 2 * kCoefLds + 2 * kCarryLds; }
 
-template <int MT, bool SMALL>
-__global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict__ tracks,
+// PAIRS: items per workgroup (2 or 4); RING: piece buffers per pair (a power of two; RING-1 pieces in flight)
+template <int MT, bool SMALL, int PAIRS, int RING>
+__global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split(const TrackDesc *__restrict__ tracks,
                                                      const RateDev *__restrict__ rates,
                                                      const FusedItem *__restrict__ items, HopRec *__restrict__ recs,
                                                      uint2 *__restrict__ cands, unsigned *__restrict__ cand_cnt,
                                                      unsigned *__restrict__ tpb, unsigned *__restrict__ overflow,
                                                      unsigned long long *__restrict__ peaks, int wave_map)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // kSplitLds
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // split_lds(PAIRS, RING)
+    constexpr int D = RING - 1;  // prefetch distance in pieces
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int pair = wave_map ? wave >> 1 : wave & 3;
-    const bool tp_role = wave_map ? (wave & 1) != 0 : wave >= 4;
-    const uint32_t item_idx = blockIdx.x * 4 + pair;
+    const int pair = (wave_map & 1) ? wave >> 1 : wave % PAIRS;
+    // wave_map bit 3: swap the roles in every other workgroup, so that a SIMD that always receives the same wave
+    // index of every workgroup still gets both kinds of work
+    const bool swap = (wave_map & 8) && (((blockIdx.x >> 8) ^ (blockIdx.x >> 3) ^ blockIdx.x) & 1);
+    const bool tp_role = ((wave_map & 1) ? (wave & 1) != 0 : wave >= PAIRS) != swap;
+    const uint32_t item_idx = blockIdx.x * PAIRS + pair;
     const FusedItem it = items[item_idx];
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
@@ -765,8 +770,8 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
     const int row = lane < n_rows ? lane : last_row;
     const uint64_t h = it.first_hop + row;
     const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * 8ull;
-    char *pbuf = smem + pair * 4 * kPieceLds;  // [4][8 KiB]: piece k lives in buffer k mod 4
-    char *abuf = smem + 16 * kPieceLds;        // [2][9 KiB]
+    char *pbuf = smem + pair * RING * kPieceLds;   // [RING][8 KiB]: piece k lives in buffer k mod RING
+    char *abuf = smem + PAIRS * RING * kPieceLds;  // [2][9 KiB]
     char *gbuf = abuf + 2 * kCoefLds;          // [2][1 KiB]
     const char *gsrc = reinterpret_cast<const char *>(r.g);
     const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
@@ -786,7 +791,7 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
     const unsigned rd_swz = (lane >> 1) & 7;
     auto issue_piece = [&](int k) {
         const char *src = wave_base + static_cast<size_t>(k) * 128;
-        char *dst = pbuf + (k & 3) * kPieceLds + jbase * 1024;
+        char *dst = pbuf + (k & (RING - 1)) * kPieceLds + jbase * 1024;
 #pragma unroll
         for (int j = 0; j < 4; j++) dma16(src, dma_off[j], dst + j * 1024);
     };
@@ -800,7 +805,7 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
     auto read_piece = [&](int k) {
         uint4v u[8];
 #pragma unroll
-        for (int c = 0; c < 8; c++) u[c] = lds_ld128(rd_off[c] + static_cast<unsigned>(k & 3) * kPieceLds, 0);
+        for (int c = 0; c < 8; c++) u[c] = lds_ld128(rd_off[c] + static_cast<unsigned>(k & (RING - 1)) * kPieceLds, 0);
         asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(u[0]), "+v"(u[1]), "+v"(u[2]), "+v"(u[3]), "+v"(u[4]), "+v"(u[5]), "+v"(u[6]), "+v"(u[7]) : : "memory");
 #pragma unroll
         for (int c = 0; c < 8; c++)
@@ -808,8 +813,8 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
     };
     // everything this wave has in flight except the newest piece (its four DMAs are always the last ones issued)
     auto wait_step = [&](int k) {
-        if (k + 2 <= T) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-        else if (k < T) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        if (D >= 3 && k + 2 <= T) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        else if (D >= 2 && k < T) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
 
@@ -846,15 +851,14 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
             ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
         }
         if (pair == 0) dma16(gsrc, lane16, gbuf);
-        issue_piece(0);
-        issue_piece(1);
-        issue_piece(2);
+#pragma unroll
+        for (int d = 0; d < D; d++) issue_piece(d);
 
         auto kw_step = [&](int k, auto short_c) {
             constexpr bool SHORT = decltype(short_c)::value;
             wait_step(k);
             __builtin_amdgcn_s_barrier();
-            const char *my_lds = pbuf + (k & 3) * kPieceLds + lane * 128;
+            const char *my_lds = pbuf + (k & (RING - 1)) * kPieceLds + lane * 128;
             read_piece(k);
             if (rem && k == T_full) {
                 const char *gk = gbuf + (k & 1) * kCarryLds;
@@ -872,7 +876,7 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
                 }
             }
             if (k < T && pair == 0) dma16(gsrc + static_cast<size_t>(k + 1) * 512, lane16, gbuf + ((k + 1) & 1) * kCarryLds);
-            if (k + 3 <= T) issue_piece(k + 3);
+            if (k + D <= T) issue_piece(k + D);
             if (k < T_full && !(wave_map & 2)) {
                 const unsigned g_at = lds_addr(gbuf) + static_cast<unsigned>(k & 1) * kCarryLds;  // broadcast reads
                 struct GC { uint4v r[4]; };
@@ -995,12 +999,11 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int ksx = 0; ksx < 3; ksx++)
-                if (((mt * 3 + ksx) & 3) == pair)
+                if ((mt * 3 + ksx) % PAIRS == pair)
                     dma16(asrc + (mt * 3 + ksx) * 1024, lane16, dst + (mt * 3 + (kmod3 + 2 + ksx) % 3) * 1024);
     };
-    issue_piece(0);
-    issue_piece(1);
-    issue_piece(2);
+#pragma unroll
+    for (int d = 0; d < D; d++) issue_piece(d);
 
     auto tp_step = [&](int k, auto slot_c) {
         constexpr int KK = decltype(slot_c)::value;  // k mod 3
@@ -1011,7 +1014,7 @@ __global__ void __launch_bounds__(512) k_fused_split(const TrackDesc *__restrict
             issue_coeff(pat, k, KK);
             pat = pat + 1 == NP ? 0 : pat + 1;
         }
-        if (k + 3 <= T) issue_piece(k + 3);
+        if (k + D <= T) issue_piece(k + D);
         if (wave_map & 4) return;
         make_frags(slot_c);
         {
@@ -1196,17 +1199,31 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
 
 int fused_tp_class(int tp_mt, int tp_last_rows) { return (tp_mt - 1) * 2 + (tp_last_rows <= 8 ? 1 : 0); }
 
+template <int MT, bool SMALL, int PAIRS, int RING>
+static void launch_split_geom(uint32_t n_items, hipStream_t st, const TrackDesc *tracks, const RateDev *rates,
+                              const FusedItem *items, HopRec *recs, uint2 *cands, const FusedScratch &fs,
+                              unsigned long long *peaks, int wave_map)
+{
+    constexpr int lds = split_lds(PAIRS, RING);
+    // more than 64 KiB of dynamic LDS has to be asked for once per kernel
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_split<MT, SMALL, PAIRS, RING>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)attr;
+    k_fused_split<MT, SMALL, PAIRS, RING><<<dim3(n_items / PAIRS), dim3(PAIRS * 128), lds, st>>>(
+        tracks, rates, items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, wave_map);
+}
+
+// HR_SPLIT_GEOM: 0 = four pairs per workgroup, ring of four piece buffers (148 KiB LDS: one workgroup per CU);
+// 1 = two pairs, ring of two (52 KiB, <= 168 VGPRs: three workgroups per CU = three waves per SIMD)
 template <int MT, bool SMALL>
 static void launch_split_case(dim3 grid, hipStream_t st, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
                               HopRec *recs, uint2 *cands, const FusedScratch &fs, unsigned long long *peaks)
 {
-    // more than 64 KiB of dynamic LDS has to be asked for once per kernel
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_split<MT, SMALL>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, kSplitLds);
-    (void)attr;
     static const int wave_map = std::getenv("HR_WAVE_MAP") ? std::atoi(std::getenv("HR_WAVE_MAP")) : 0;
-    k_fused_split<MT, SMALL><<<grid, dim3(512), kSplitLds, st>>>(tracks, rates, items, recs, cands, fs.cand_cnt, fs.tpb,
-                                                                  fs.overflow, peaks, wave_map);
+    static const int geom = std::getenv("HR_SPLIT_GEOM") ? std::atoi(std::getenv("HR_SPLIT_GEOM")) : 0;
+    const uint32_t n_items = grid.x * 4;  // (the host pads every run of items to a multiple of four)
+    if (geom == 1) launch_split_geom<MT, SMALL, 2, 2>(n_items, st, tracks, rates, items, recs, cands, fs, peaks, wave_map);
+    else launch_split_geom<MT, SMALL, 4, 4>(n_items, st, tracks, rates, items, recs, cands, fs, peaks, wave_map);
 }
 
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
