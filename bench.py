@@ -52,13 +52,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--tracks", type=int, default=1000, help="tracks per GPU (default: BASELINE config 2)")
+    ap.add_argument("--tracks", type=int, default=0, help="tracks per GPU (default: 1000 = BASELINE config 2; 1250 for config3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--pcm-format", choices=["f32", "s16"], default="f32",
                     help="f32 is the BASELINE workload; s16 measures the widening path (a side figure, labelled as such)")
-    ap.add_argument("--workload", choices=["config2", "config4", "config5"], default="config2",
-                    help="config2 = the BASELINE bench workload; config4 = 96 kHz 24-bit 5.1 tracks (a side figure: split into "
+    ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config2",
+                    help="config2 = the BASELINE bench workload; config3 = one GPU's share of the 10,000-track 48 kHz batch "
+                         "(1,250 tracks, 86.4 GB; a side figure); config4 = 96 kHz 24-bit 5.1 tracks (a side figure: split into "
                          "stereo f32 planes on the device, then the same fused kernel); config5 = one 10-hour 48 kHz stereo stream, "
                          "whole and as 8 time shards on this one device (a side figure)")
     ap.add_argument("--hours", type=float, default=10.0, help="config5: length of the stream")
@@ -82,7 +83,10 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    n_tracks = args.tracks
+    global FS
+    if args.workload == "config3":
+        FS = 48000
+    n_tracks = args.tracks or (1250 if args.workload == "config3" else 1000)
     meter = hr.Meter(device=local, engine=args.engine)
     if args.workload == "config4":
         run_config4(args, meter, dev, n_tracks, rank)
@@ -93,19 +97,21 @@ def main():
         meter.close()
         return
     frames = FS * SECONDS
-    pcm = torch.empty((n_tracks, frames, CH), dtype=torch.float32, device=dev)
+    # HR_BENCH_OFFSET (experiments): byte offset of every track inside its slot, to see what cache-line alignment is worth
+    boff = int(os.environ.get("HR_BENCH_OFFSET", "0"))
+    pcm = torch.empty((n_tracks, frames + (16 if boff else 0), CH), dtype=torch.float32, device=dev)
     for i in range(n_tracks):
-        meter.synth_fill(pcm[i].data_ptr(), 1000 + rank * n_tracks + i, FS, CH, frames)
+        meter.synth_fill(pcm[i].data_ptr() + boff, 1000 + rank * n_tracks + i, FS, CH, frames)
     torch.cuda.synchronize()
     if args.pcm_format == "s16":
         pcm16 = torch.empty((n_tracks, frames, CH), dtype=torch.int16, device=dev)
         for i in range(n_tracks):
-            pcm16[i] = torch.clamp(torch.round(pcm[i] * 32768.0), -32768, 32767).to(torch.int16)
+            pcm16[i] = torch.clamp(torch.round(pcm[i][:frames] * 32768.0), -32768, 32767).to(torch.int16)
         torch.cuda.synchronize()
         specs = [hr.TrackSpec(pcm16[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_S16, frames=frames) for i in range(n_tracks)]
         bytes_per_step = n_tracks * frames * CH * 2
     else:
-        specs = [hr.TrackSpec(pcm[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_F32, frames=frames) for i in range(n_tracks)]
+        specs = [hr.TrackSpec(pcm[i].data_ptr() + boff, FS, channels=CH, fmt=hr.FMT_F32, frames=frames) for i in range(n_tracks)]
         bytes_per_step = n_tracks * frames * CH * 4
 
     def barrier():
@@ -140,7 +146,7 @@ def main():
         # committed measurement (profiles/r1_fused_hbm_traffic.json, bytes per track) scaled to this launch
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_fused_hbm_traffic.json")
-        if os.path.exists(tpath):
+        if os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32":
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_track"] * n_tracks
             traffic_src = "profiles/r1_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
@@ -149,8 +155,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s 44.1 kHz stereo {args.pcm_format} PCM resident in HBM "
-                                   "(BASELINE configs[1]); per-track integrated LUFS (ebur128 gating) + dBTP (192 kHz)",
+            "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s {FS / 1000:g} kHz stereo {args.pcm_format} PCM resident in HBM "
+                                   f"(BASELINE configs[{2 if args.workload == 'config3' else 1}]); per-track integrated LUFS (ebur128 gating) + dBTP (192 kHz)",
                        "tracks_per_gpu": n_tracks, "bytes_per_gpu": bytes_per_step, "parallelism": f"track-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -159,7 +165,7 @@ def main():
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32":
+        if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2":
             threads = min(16, os.cpu_count() or 1)
             base, ref, cpu_tracks = cpu_baseline(threads, threads)
             line["cpu_baseline"] = base
@@ -171,7 +177,7 @@ def main():
             # the boundary also takes host buffers: same tracks from pinned host memory, H2D staging included
             nh = min(args.host_pcm, n_tracks)
             host = torch.empty((nh, frames, CH), dtype=torch.float32, pin_memory=True)
-            host.copy_(pcm[:nh])
+            host.copy_(pcm[:nh, :frames])
             torch.cuda.synchronize()
             hspecs = [hr.TrackSpec(host[i], FS) for i in range(nh)]
             hres = meter.analyze_batch(hspecs)
