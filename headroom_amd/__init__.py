@@ -72,7 +72,7 @@ class HrPcmInfo(C.Structure):
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
-           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass"]
+           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass", "hr_pcm_gain_file"]
 
 _lib = None
 
@@ -115,6 +115,7 @@ def lib():
     L.hr_report_csv_header.argtypes = [C.c_char_p, C.c_size_t]
     L.hr_report_csv_row.argtypes = [C.c_char_p, C.POINTER(HrAnalysis), C.c_char_p, C.c_size_t]
     L.hr_loudnorm_first_pass.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_size_t, C.POINTER(HrResult)]
+    L.hr_pcm_gain_file.argtypes = [C.c_void_p, C.c_char_p, C.c_double, C.POINTER(C.c_uint64)]
     L.hr_apply_gain.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_double, C.c_int, C.c_void_p, C.POINTER(C.c_uint64)]
     L.hr_synth_fill.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64]
     L.hr_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]
@@ -270,6 +271,12 @@ class Meter:
         _check(lib().hr_apply_gain(self._h, C.byref(spec.c), gain_db, int(big_endian), out.ctypes.data_as(C.c_void_p),
                                    C.byref(clipped)), "hr_apply_gain")
         return out[:nbytes], int(clipped.value)
+
+    def gain_file(self, path, gain_db):
+        """hr_pcm_gain_file: rewrites a WAV / AIFF file in place with the gain applied (24-bit PCM); returns clipped."""
+        clipped = C.c_uint64(0)
+        _check(lib().hr_pcm_gain_file(self._h, str(path).encode(), gain_db, C.byref(clipped)), "hr_pcm_gain_file")
+        return int(clipped.value)
 
     def synth_fill(self, device_ptr, seed, sample_rate, channels, frames):
         _check(lib().hr_synth_fill(self._h, C.c_void_p(int(device_ptr)), seed, sample_rate, channels, frames), "hr_synth_fill")

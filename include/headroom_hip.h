@@ -251,6 +251,12 @@ int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_res
  * pointer.  *clipped (may be NULL) receives the number of samples that saturated. */
 int hr_apply_gain(hr_ctx *ctx, const hr_track *track, double gain_db, int out_big_endian, void *out, uint64_t *clipped);
 
+/* The same for a WAV / AIFF / AIFF-C file, in place, as apply_gain_ffmpeg does (src/processor.rs:53-87): the file is
+ * rewritten as 24-bit PCM (WAV little endian, AIFF big endian) into `<stem>.tmp.<ext>` beside it and renamed over
+ * the original; every chunk other than the format / sound chunks (bext, LIST, ID3, markers ...) is copied through in
+ * place.  Files whose result would pass 4 GiB: HR_ERR_TOO_LARGE (no RF64).  Compressed files: HR_ERR_FORMAT. */
+int hr_pcm_gain_file(hr_ctx *ctx, const char *path, double gain_db, uint64_t *clipped);
+
 /* One line of the CSV report, src/report.rs:29-59: the header record, and the record of one analysed file
  * (labels: GainMethod::format_label / method_label, src/analyzer.rs:80-100; numbers with one decimal, headroom and
  * gain signed; fields quoted as the csv crate does by default).  Return the length written (without the NUL), or

@@ -68,3 +68,90 @@ def test_apply_gain_rejects_bad_arguments(meter):
     x = np.zeros((16, 2), np.float32)
     with pytest.raises(hr.HeadroomError):
         meter.apply_gain(hr.TrackSpec(x, 48000), float("nan"))
+
+
+# ---- file level: apply_gain_ffmpeg (src/processor.rs:53-87) ---------------------------------------------------------
+
+def _chunks(raw, big):
+    import struct
+    pos, out = 12, []
+    while pos + 8 <= len(raw):
+        size = struct.unpack(">I" if big else "<I", raw[pos + 4:pos + 8])[0]
+        out.append((raw[pos:pos + 4], raw[pos + 8:pos + 8 + size]))
+        pos += 8 + size + (size & 1)
+    return out
+
+
+def test_gain_file_wav_in_place(oracle, meter, tmp_path):
+    import containers
+    x = signals.seeded_noise(81, 30001, 2, -6.0).astype(np.float64)
+    bext = (b"bext", b"B" * 603)                       # odd size: padded
+    lst = (b"LIST", b"INFOINAM\x06\x00\x00\x00title\x00")
+    raw, seen = containers.wav_bytes(x, 44100, "s16", extra_chunks=[bext, lst])
+    raw += b"id3 " + (5).to_bytes(4, "little") + b"ID3v2\x00"   # a chunk AFTER the samples
+    raw = raw[:4] + (len(raw) - 8).to_bytes(4, "little") + raw[8:]
+    path = tmp_path / "song.wav"
+    path.write_bytes(raw)
+    clipped = meter.gain_file(path, 3.25)
+    ref, ref_clip = oracle.apply_gain(seen, 44100, 3.25)
+    out = path.read_bytes()
+    assert not (tmp_path / "song.tmp.wav").exists() and clipped == ref_clip
+    assert out[:4] == b"RIFF" and int.from_bytes(out[4:8], "little") == len(out) - 8
+    ck = _chunks(out, False)
+    assert [t for t, _ in ck] == [b"fmt ", b"bext", b"LIST", b"data", b"id3 "]
+    assert ck[1][1] == bext[1] and ck[2][1] == lst[1] and ck[4][1] == b"ID3v2"
+    assert ck[3][1] == ref.tobytes()
+    rc, info = hr.pcm_probe(out)
+    assert rc == 0 and info["fmt"] == hr.FMT_S24 and info["frames"] == 30001 and info["channels"] == 2 and info["sample_rate"] == 44100
+    # the rewritten file measures like the gained signal
+    lf = hr.LoadedFile(str(path))
+    got = meter.analyze_batch([lf])[0]
+    lf.close()
+    want = oracle.measure(ref, 44100, channels=2, fmt=oracle.FMT_S24)
+    assert abs(got["integrated_lufs"] - want["integrated_lufs"]) < 1e-6 and got["peak_per_ch"] == want["peak_per_ch"]
+
+
+def test_gain_file_wav_5_1_keeps_the_channel_mask(oracle, meter, tmp_path):
+    import containers
+    x = signals.seeded_noise(82, 4800, 6, -12.0).astype(np.float64)
+    raw, seen = containers.wav_bytes(x, 48000, "f32", extensible_mask=0x60F)
+    path = tmp_path / "surround.wav"
+    path.write_bytes(raw)
+    meter.gain_file(path, -2.0)
+    out = path.read_bytes()
+    rc, info = hr.pcm_probe(out)
+    assert rc == 0 and info["fmt"] == hr.FMT_S24 and info["channel_mask"] == 0x60F and info["channels"] == 6
+    ref, _ = oracle.apply_gain(seen, 48000, -2.0)
+    assert dict(_chunks(out, False))[b"data"] == ref.tobytes()
+
+
+@pytest.mark.parametrize("aifc", [None, b"sowt", b"fl32"])
+def test_gain_file_aiff_in_place(oracle, meter, tmp_path, aifc):
+    import containers
+    x = signals.seeded_noise(83, 12345, 2, -9.0).astype(np.float64)
+    kind = "f32" if aifc == b"fl32" else "s16"
+    raw, seen = containers.aiff_bytes(x, 48000, kind, aifc=aifc)
+    raw += b"ID3 " + (6).to_bytes(4, "big") + b"ID3v2."
+    raw = raw[:4] + (len(raw) - 8).to_bytes(4, "big") + raw[8:]
+    path = tmp_path / "take.aif"
+    path.write_bytes(raw)
+    clipped = meter.gain_file(path, 1.5)
+    out = path.read_bytes()
+    assert not (tmp_path / "take.tmp.aif").exists()
+    assert out[:4] == b"FORM" and out[8:12] == b"AIFF" and int.from_bytes(out[4:8], "big") == len(out) - 8
+    ck = _chunks(out, True)
+    assert [t for t, _ in ck] == [b"COMM", b"SSND", b"ID3 "] and ck[2][1] == b"ID3v2."
+    ref, ref_clip = oracle.apply_gain(seen, 48000, 1.5, True)
+    assert clipped == ref_clip and ck[1][1][8:] == ref.tobytes()
+    rc, info = hr.pcm_probe(out)
+    assert rc == 0 and info["fmt"] == hr.FMT_S24 and info["frames"] == 12345 and info["big_endian"] == 1 and info["sample_rate"] == 48000
+
+
+def test_gain_file_rejects_what_it_cannot_rewrite(meter, tmp_path):
+    p = tmp_path / "not_audio.wav"
+    p.write_bytes(b"RIFF\x04\x00\x00\x00WAVE")
+    with pytest.raises(hr.HeadroomError):
+        meter.gain_file(p, 1.0)
+    with pytest.raises(hr.HeadroomError):
+        meter.gain_file(tmp_path / "missing.wav", 1.0)
+    assert p.read_bytes() == b"RIFF\x04\x00\x00\x00WAVE"
