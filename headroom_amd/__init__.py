@@ -202,6 +202,22 @@ class TrackSpec:
         self.c = HrTrack(ptr, frames, sample_rate, channels, fmt, wptr, flags, 0)
 
 
+class TrackBatch:
+    """An hr_track array and its hr_result array, marshalled once (Meter.analyze_prepared)."""
+
+    def __init__(self, specs):
+        self.specs = list(specs)  # keeps the PCM buffers alive
+        self.n = len(self.specs)
+        self.tracks = (HrTrack * max(self.n, 1))(*[s.c for s in self.specs])
+        self.out = (HrResult * max(self.n, 1))()
+
+    def statuses(self):
+        return [int(self.out[i].status) for i in range(self.n)]
+
+    def results(self):
+        return [_result_dict(self.out[i], self.specs[i].channels or 0) for i in range(self.n)]
+
+
 class Meter:
     """A per-GPU context of the meter (hr_init / hr_destroy)."""
 
@@ -234,6 +250,11 @@ class Meter:
         out = (HrResult * max(n, 1))()
         _check(lib().hr_analyze_batch(self._h, arr, n, out), "hr_analyze_batch")
         return [_result_dict(out[i], specs[i].channels or 0) for i in range(n)]
+
+    def analyze_prepared(self, batch):
+        """hr_analyze_batch on a TrackBatch: the descriptor and result arrays are the caller's and live across calls, as
+        they would in a C or Rust caller; nothing is converted.  batch.results() turns the last results into dicts."""
+        _check(lib().hr_analyze_batch(self._h, batch.tracks, batch.n, batch.out), "hr_analyze_batch")
 
     def loudnorm_first_pass(self, specs):
         """hr_loudnorm_first_pass: what `ffmpeg -af loudnorm=print_format=json` measures (src/analyzer.rs:253-267)."""
