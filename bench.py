@@ -74,11 +74,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # HR_BENCH_ONE_DEVICE=1 (rehearsal of the multi-rank path on a one-GPU box): every rank uses cuda:0 and the
+    # timing collectives run over gloo
+    rehearsal = os.environ.get("HR_BENCH_ONE_DEVICE") == "1"
+    if rehearsal:
+        local = 0
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     else:
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -134,7 +142,7 @@ def main():
     elapsed = time.perf_counter() - t0
     res = batch.results()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert all(r["status"] == 0 for r in res)
