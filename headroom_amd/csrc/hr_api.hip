@@ -77,13 +77,13 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps, unit_tap;
 
     // workspace (grow-only)
-    DevBuf widened, resampled, parents_d, counters, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
     std::vector<FusedItem> h_fitems;
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
-    std::vector<WorkItem> h_ovf_items;
+    std::vector<WorkItem> h_ovf_items, h_gate_items;
     bool serial_tail = false;  // HR_SERIAL_TAIL=1 (timing experiments): tail kernels before the fused kernel, not beside it
     bool split = false;  // HR_FUSED_SPLIT=1: k_fused_split (K-weighting and true peak in separate waves) instead of k_fused_f32s
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
@@ -188,6 +188,7 @@ struct Group {
     std::vector<TrackDesc> descs;
     std::vector<int> fmts;  // per desc
     uint64_t rec_slots = 0, hop_slots = 0, blk_slots = 0;  // totals: (hop, channel) records / sums, blocks
+    uint32_t part_slots = 0;  // gating chunks
     std::vector<uint32_t> parents;  // descriptors with role 1 (measured through stereo planes)
 };
 
@@ -215,6 +216,9 @@ void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bo
     g.rec_slots += (d.n_hops + kPreRec) * d.ch;
     g.hop_slots += (d.n_hops + kPreHop) * d.ch;
     g.blk_slots += d.n_blocks;
+    d.part_base = g.part_slots;
+    d.n_parts = static_cast<uint32_t>(std::max<uint64_t>(1, (d.n_blocks + kGateChunk - 1) / kGateChunk));
+    g.part_slots += d.n_parts;
     if (t.ch_weight) for (int c = 0; c < t.channels; c++) d.w[c] = t.ch_weight[c];
     else default_weights(t.channels, d.w);
     g.descs.push_back(d);
@@ -410,17 +414,31 @@ int run_gating(hr_ctx *ctx, Group &g, bool finalize)
     hipStream_t st = ctx->stream;
     const uint32_t nt = static_cast<uint32_t>(g.descs.size());
     if (!nt) return HR_OK;
-    if (!ctx->hist.ensure(static_cast<size_t>(nt) * kEbuBins * sizeof(uint32_t))) return HR_ERR_OOM;
-    if (!ctx->outs.ensure(static_cast<size_t>(nt) * sizeof(TrackOut))) return HR_ERR_OOM;
+    const size_t hist_bytes = static_cast<size_t>(nt) * kEbuBins * sizeof(uint32_t);
+    if (!ctx->hist.ensure(hist_bytes) || !ctx->outs.ensure(static_cast<size_t>(nt) * sizeof(TrackOut)) ||
+        !ctx->gate_parts.ensure(static_cast<size_t>(g.part_slots) * sizeof(GatePart)) || (finalize && !ctx->st_hist.ensure(hist_bytes)))
+        return HR_ERR_OOM;
+    // one workgroup per chunk of kGateChunk blocks: a 3-minute track is one chunk, a 10-hour stream 22
+    std::vector<WorkItem> &items = ctx->h_gate_items;  // (outlives the asynchronous copy)
+    items.clear();
+    for (uint32_t i = 0; i < nt; i++)
+        for (uint32_t c = 0; c < g.descs[i].n_parts; c++) items.push_back({i, c, static_cast<uint64_t>(c) * kGateChunk});
+    int rc = upload(ctx->gate_items, items.data(), items.size() * sizeof(WorkItem), st);
+    if (rc) return rc;
     const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
-    launch_block_hist(dt, nt, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
-                      ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->outs.as<TrackOut>(), st);
+    const WorkItem *di = ctx->gate_items.as<WorkItem>();
+    const uint32_t ni = static_cast<uint32_t>(items.size());
+    HIPCHK(hipMemsetAsync(ctx->hist.p, 0, hist_bytes, st));
+    launch_block_hist(dt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
+                      ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), st);
+    launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
+                      ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
+                      ctx->gate_parts.as<GatePart>(), !finalize, ctx->outs.as<TrackOut>(), st);
     if (finalize) {
-        launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
-                          ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
-                          ctx->outs.as<TrackOut>(), st);
-        launch_range_stats(dt, nt, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
-                           ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->outs.as<TrackOut>(), st);
+        HIPCHK(hipMemsetAsync(ctx->st_hist.p, 0, hist_bytes, st));
+        launch_range_stats(dt, nt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
+                           ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->st_hist.as<uint32_t>(),
+                           ctx->gate_parts.as<GatePart>(), ctx->outs.as<TrackOut>(), st);
     }
     HIPCHK(hipGetLastError());
     return HR_OK;
@@ -685,7 +703,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->unit_tap, &ctx->tracks_d,
-                      &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -977,7 +995,7 @@ int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_r
     if (!ctx->blk_powers.ensure(sizeof(double))) return HR_ERR_OOM;
     launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(),
                       ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(),
-                      ctx->ln_bounds.as<double>(), ctx->outs.as<TrackOut>(), st);
+                      ctx->ln_bounds.as<double>(), nullptr, false, ctx->outs.as<TrackOut>(), st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

@@ -12,6 +12,16 @@ constexpr int kPreHop = 3;   // hop sums kept in front of hop 0 (complete the 3 
 constexpr int kHalo = 16;    // frames of FIR halo on each side of a shard
 constexpr int kEbuBins = 8001;
 constexpr int kLnBins = 1000;
+constexpr uint32_t kGateChunk = 16384;  // 400 ms blocks (and 3 s windows) per gating workgroup: a 3-minute track is one chunk
+
+// what one gating chunk hands to the per-track finalisation (summed there in chunk order: reproducible)
+struct GatePart {
+    double sum_kept;             // power of the blocks above the absolute gate
+    unsigned long long n_kept;
+    double st_sum_kept;          // the same for the 3 s windows (loudness range)
+    unsigned long long st_n_kept;
+    double max_m_power, max_s_power;
+};
 
 // per sample rate, device resident
 struct RateDev {
@@ -57,6 +67,7 @@ struct TrackDesc {
     uint8_t role;          // 0 ordinary track; 1 parent of stereo planes (measured through them: no work items of its
                            // own, only hop-sum slots and gating); 2 stereo plane of a parent
     uint32_t first_plane;  // role 1: index of the first of its (ch+1)/2 consecutive plane descriptors
+    uint32_t part_base, n_parts;  // gating chunks of kGateChunk blocks (one workgroup each): slots of their partial sums
     float w[kMaxCh];
 };
 

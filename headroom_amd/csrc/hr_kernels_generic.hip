@@ -243,20 +243,18 @@ __device__ __forceinline__ unsigned long long block_reduce_sum_u64(unsigned long
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, int gate_mode,
-                                                    const double *__restrict__ hop_sums,
+__global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
+                                                    int gate_mode, const double *__restrict__ hop_sums,
                                                     const double *__restrict__ ln_bounds,
                                                     double *__restrict__ block_powers,
-                                                    uint32_t *__restrict__ hist, TrackOut *__restrict__ outs)
+                                                    uint32_t *__restrict__ hist, GatePart *__restrict__ parts)
 {
     __shared__ double shd[256];
     __shared__ unsigned long long shu[256];
-    const TrackDesc &t = tracks[blockIdx.x];
+    const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first block of the chunk
+    const TrackDesc &t = tracks[it.track];
     const int C = t.ch;
-    const int nbins = gate_mode == 2 ? kLnBins : kEbuBins;
-    uint32_t *hg = hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hg[i] = 0;
-    __syncthreads();
+    uint32_t *hg = hist + static_cast<size_t>(it.track) * kEbuBins;  // zeroed by the host before the launch
 
     const double bins = gate_mode == 2 ? static_cast<double>(4 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
                                        : static_cast<double>(static_cast<uint64_t>(t.fs) * 4 / 10);
@@ -264,7 +262,8 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
     double sum_kept = 0.0;
     unsigned long long n_kept = 0;
     const double *H = hop_sums + t.hop_base + kPreHop * C;
-    for (uint64_t jj = threadIdx.x; jj < t.n_blocks; jj += blockDim.x) {
+    const uint64_t jj_end = it.first + kGateChunk < t.n_blocks ? it.first + kGateChunk : t.n_blocks;
+    for (uint64_t jj = it.first + threadIdx.x; jj < jj_end; jj += blockDim.x) {
         const int64_t j = t.blk_first + static_cast<int64_t>(jj);
         double power = gate_mode == 2 ? 0.0 : 1e-12;
         for (int c = 0; c < C; c++) {
@@ -301,13 +300,9 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
     const double sk = block_reduce_sum(sum_kept, shd);
     const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
     if (threadIdx.x == 0) {
-        TrackOut &o = outs[blockIdx.x];
-        o.sum_kept = sk;
-        o.n_kept = nk;
-        o.n_blocks = t.n_blocks;
-        o.mean_energy = 0;
-        o.rel_energy = 0;
-        o.n_gated_final = 0;
+        GatePart &p = parts[t.part_base + it.pad];
+        p.sum_kept = sk;
+        p.n_kept = nk;
     }
 }
 
@@ -321,6 +316,7 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
                                                     const double *__restrict__ ebu_energy,
                                                     const double *__restrict__ ln_energy,
                                                     const double *__restrict__ ln_bounds,
+                                                    const GatePart *__restrict__ parts, int reduce_only,
                                                     TrackOut *__restrict__ outs)
 {
     __shared__ double shd[256];
@@ -328,6 +324,22 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
     const TrackDesc &t = tracks[blockIdx.x];
     TrackOut &o = outs[blockIdx.x];
     const uint32_t *hg = hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
+    // the chunks' partial sums, in chunk order (n_parts == 0: `outs` already carries sums reduced over shards)
+    if (t.n_parts) {
+        if (threadIdx.x == 0) {
+            double sk = 0.0;
+            unsigned long long nk = 0;
+            for (uint32_t c = 0; c < t.n_parts; c++) { sk += parts[t.part_base + c].sum_kept; nk += parts[t.part_base + c].n_kept; }
+            o.sum_kept = sk;
+            o.n_kept = nk;
+            o.n_blocks = t.n_blocks;
+            o.mean_energy = 0;
+            o.rel_energy = 0;
+            o.n_gated_final = 0;
+        }
+        __syncthreads();
+    }
+    if (reduce_only) return;
     const unsigned long long n_kept = o.n_kept;
     if (n_kept == 0) return;  // uniform across the block
 
@@ -428,23 +440,21 @@ __device__ __forceinline__ double block_reduce_max(double v, double *sh)
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict__ tracks, int gate_mode,
-                                                     const double *__restrict__ hop_sums,
+__global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
+                                                     int gate_mode, const double *__restrict__ hop_sums,
                                                      const double *__restrict__ block_powers,
-                                                     const double *__restrict__ ln_bounds,
-                                                     const double *__restrict__ ln_energy, TrackOut *__restrict__ outs)
+                                                     const double *__restrict__ ln_bounds, uint32_t *__restrict__ st_hist,
+                                                     GatePart *__restrict__ parts)
 {
     __shared__ uint32_t hh[kEbuBins];
     __shared__ double shd[256];
     __shared__ unsigned long long shu[256];
-    __shared__ int lo_bin, hi_bin;
-    const TrackDesc &t = tracks[blockIdx.x];
-    TrackOut &o = outs[blockIdx.x];
+    const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first window / block of the chunk
+    const TrackDesc &t = tracks[it.track];
     const int C = t.ch;
     const bool ln = gate_mode == 2;
     const int nbins = ln ? kLnBins : kEbuBins;
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
-    if (threadIdx.x == 0) { lo_bin = nbins; hi_bin = ln ? nbins : -1; }
     __syncthreads();
     const uint64_t n_s = t.n_hops >= 30 ? t.n_hops - 29 : 0;
     const double bins = ln ? static_cast<double>(30 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
@@ -452,7 +462,8 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
     const double *H = hop_sums + t.hop_base + kPreHop * C;
     double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
     unsigned long long n_kept = 0;
-    for (uint64_t j = threadIdx.x; j < n_s; j += blockDim.x) {
+    const uint64_t j_end = it.first + kGateChunk < n_s ? it.first + kGateChunk : n_s;
+    for (uint64_t j = it.first + threadIdx.x; j < j_end; j += blockDim.x) {
         double power = ln ? 0.0 : 1e-12;
         for (int c = 0; c < C; c++) {
             if (t.w[c] == 0.0f) continue;
@@ -480,12 +491,53 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
             atomicAdd(&hh[lo], 1u);
         }
     }
-    for (uint64_t jj = threadIdx.x; jj < t.n_blocks; jj += blockDim.x) {
+    const uint64_t b_end = it.first + kGateChunk < t.n_blocks ? it.first + kGateChunk : t.n_blocks;
+    for (uint64_t jj = it.first + threadIdx.x; jj < b_end; jj += blockDim.x) {
         const double p = block_powers[t.blk_base + jj];
         max_m = p > max_m ? p : max_m;
     }
     max_s = block_reduce_max(max_s, shd);
     max_m = block_reduce_max(max_m, shd);
+    const double sk = block_reduce_sum(sum_kept, shd);
+    const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
+    // the chunk's histogram joins the track's (zeroed by the host before the launch)
+    uint32_t *hg = st_hist + static_cast<size_t>(it.track) * kEbuBins;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (hh[i]) atomicAdd(&hg[i], hh[i]);
+    if (threadIdx.x == 0) {
+        GatePart &p = parts[t.part_base + it.pad];
+        p.st_sum_kept = sk;
+        p.st_n_kept = nk;
+        p.max_s_power = max_s;
+        p.max_m_power = max_m;
+    }
+}
+
+// the track's loudness range from its complete short-term histogram; one workgroup per track
+__global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict__ tracks, int gate_mode,
+                                                     const uint32_t *__restrict__ st_hist, const GatePart *__restrict__ parts,
+                                                     const double *__restrict__ ln_bounds,
+                                                     const double *__restrict__ ln_energy, TrackOut *__restrict__ outs)
+{
+    __shared__ double shd[256];
+    __shared__ unsigned long long shu[256];
+    __shared__ int lo_bin, hi_bin;
+    const TrackDesc &t = tracks[blockIdx.x];
+    TrackOut &o = outs[blockIdx.x];
+    const bool ln = gate_mode == 2;
+    const int nbins = ln ? kLnBins : kEbuBins;
+    const uint32_t *hh = st_hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
+    if (threadIdx.x == 0) { lo_bin = nbins; hi_bin = ln ? nbins : -1; }
+    __syncthreads();
+    double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
+    unsigned long long n_kept = 0;
+    for (uint32_t c = 0; c < t.n_parts; c++) {  // chunk order, every thread the same
+        const GatePart &p = parts[t.part_base + c];
+        sum_kept += p.st_sum_kept;
+        n_kept += p.st_n_kept;
+        max_s = p.max_s_power > max_s ? p.max_s_power : max_s;
+        max_m = p.max_m_power > max_m ? p.max_m_power : max_m;
+    }
     // first bin of the range statistics and the mean power the relative gate derives from
     int first = 0;
     double rel_energy = 0.0;
@@ -493,11 +545,9 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
     constexpr int kChunk = 32;  // bins per thread: 256 * 32 >= 8001
     const int c0 = threadIdx.x * kChunk, c1 = c0 + kChunk < nbins ? c0 + kChunk : nbins;
     if (!ln) {
-        const double sk = block_reduce_sum(sum_kept, shd);
-        const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
-        any = nk != 0;
+        any = n_kept != 0;
         if (any) {
-            double rt = sk / static_cast<double>(nk);
+            double rt = sum_kept / static_cast<double>(n_kept);
             if (!rt) rt = 1e-12;
             rel_energy = rt;
             const double rel_thr = (-0.691 + 10.0 * log10(rt)) + (-20.0);
@@ -563,19 +613,22 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
         o.st_rel_energy = rel_energy;
         o.max_m_power = max_m;
         o.max_s_power = max_s;
-        o.n_shortterm = n_s;
+        o.n_shortterm = t.n_hops >= 30 ? t.n_hops - 29 : 0;
         o.lra_low_bin = any ? lo_bin : -1;
         o.lra_high_bin = any ? hi_bin : -1;
     }
 }
 
-void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
-                        const double *block_powers, const double *ln_bounds, const double *ln_energy, TrackOut *outs,
-                        hipStream_t st)
+void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
+                        const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
+                        uint32_t *st_hist, GatePart *parts, TrackOut *outs, hipStream_t st)
 {
     if (!n_tracks) return;
-    hipLaunchKernelGGL(k_range_stats, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, hop_sums, block_powers, ln_bounds,
-                       ln_energy, outs);
+    if (n_items)
+        hipLaunchKernelGGL(k_range_stats, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, block_powers,
+                           ln_bounds, st_hist, parts);
+    hipLaunchKernelGGL(k_range_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, st_hist, parts, ln_bounds, ln_energy,
+                       outs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -781,21 +834,21 @@ void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint
     hipLaunchKernelGGL(k_gather_planes, dim3(n_parents), dim3(256), 0, st, tracks, parents, hop_sums);
 }
 
-void launch_block_hist(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *hop_sums,
-                       const double *ln_bounds, double *block_powers, uint32_t *hist, TrackOut *outs, hipStream_t st)
+void launch_block_hist(const TrackDesc *tracks, const WorkItem *items, uint32_t n_items, int gate_mode, const double *hop_sums,
+                       const double *ln_bounds, double *block_powers, uint32_t *hist, GatePart *parts, hipStream_t st)
 {
-    if (!n_tracks) return;
-    hipLaunchKernelGGL(k_block_hist, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, hop_sums, ln_bounds,
-                       block_powers, hist, outs);
+    if (!n_items) return;
+    hipLaunchKernelGGL(k_block_hist, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, ln_bounds,
+                       block_powers, hist, parts);
 }
 
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
-                       const double *ln_bounds, TrackOut *outs, hipStream_t st)
+                       const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st)
 {
     if (!n_tracks) return;
     hipLaunchKernelGGL(k_gate_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, block_powers, hist,
-                       ebu_energy, ln_energy, ln_bounds, outs);
+                       ebu_energy, ln_energy, ln_bounds, parts, reduce_only ? 1 : 0, outs);
 }
 
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
