@@ -490,3 +490,27 @@ def test_loudnorm_first_pass_matches_oracle(oracle, meters):
     check_against_oracle(oracle, m, pcm, fs)
     bad = m.loudnorm_first_pass([hr.TrackSpec(signals.seeded_noise(1, 1000, 2), 384000)])
     assert bad[0]["status"] == hr.ERR_RATE
+
+
+def test_concurrent_callers_share_one_context(oracle, meters):
+    """The drop-in caller keeps rayon's par_iter shape (src/cli.rs:407-415): many host threads, one context.  Calls are
+    serialised inside the library; every thread must get its own track's numbers back."""
+    from concurrent.futures import ThreadPoolExecutor
+    m = meters()
+    fs = 48000
+    tracks = [signals.seeded_noise(500 + i, fs * 2 + 997 * i, 2 if i % 3 else 6, -10.0 - i) for i in range(12)]
+    refs = [oracle.measure(t, fs) for t in tracks]
+
+    def work(i):
+        out = []
+        for _ in range(3):
+            out.append(m.analyze(tracks[i], fs))
+        return out
+
+    with ThreadPoolExecutor(max_workers=6) as ex:
+        got = list(ex.map(work, range(len(tracks))))
+    for i, runs in enumerate(got):
+        for g in runs:
+            assert g["status"] == 0 and g["n_blocks"] == refs[i]["n_blocks"]
+            assert abs(g["integrated_lufs"] - refs[i]["integrated_lufs"]) < 1e-6
+            assert g["peak_per_ch"] == refs[i]["peak_per_ch"]
