@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--tracks", type=int, default=0, help="tracks per GPU (default: 1000 = BASELINE config 2; 1250 for config3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0)
+    ap.add_argument("--tp-mode", choices=["swr192k", "bs1770", "sample"], default="swr192k",
+                    help="true-peak interpolator (swr192k = FFmpeg's, the BASELINE workload; the others are side figures)")
     ap.add_argument("--pcm-format", choices=["f32", "s16"], default="f32",
                     help="f32 is the BASELINE workload; s16 measures the widening path (a side figure, labelled as such)")
     ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config2",
@@ -95,7 +97,7 @@ def main():
     if args.workload == "config3":
         FS = 48000
     n_tracks = args.tracks or (1250 if args.workload == "config3" else 1000)
-    meter = hr.Meter(device=local, engine=args.engine)
+    meter = hr.Meter(device=local, engine=args.engine, tp_mode={"swr192k": 0, "bs1770": 1, "sample": 2}[args.tp_mode])
     if args.workload == "config4":
         run_config4(args, meter, dev, n_tracks, rank)
         meter.close()
@@ -166,7 +168,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s {FS / 1000:g} kHz stereo {args.pcm_format} PCM resident in HBM "
-                                   f"(BASELINE configs[{2 if args.workload == 'config3' else 1}]); per-track integrated LUFS (ebur128 gating) + dBTP (192 kHz)",
+                                   f"(BASELINE configs[{2 if args.workload == 'config3' else 1}]); per-track integrated LUFS (ebur128 gating) + dBTP ({'192 kHz' if args.tp_mode == 'swr192k' else args.tp_mode})",
                        "tracks_per_gpu": n_tracks, "bytes_per_gpu": bytes_per_step, "parallelism": f"track-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
@@ -175,7 +177,7 @@ def main():
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2":
+        if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2" and args.tp_mode == "swr192k":
             threads = min(16, os.cpu_count() or 1)
             base, ref, cpu_tracks = cpu_baseline(threads, threads)
             line["cpu_baseline"] = base

@@ -243,19 +243,24 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     // Which tracks take the fused kernel (hr_kernels_fused.hip)?  Stereo f32, 16-byte aligned, at least two
     // hops; its true-peak half additionally needs HR_TP_SWR192K and the rate's f16 tile table.  The fused
     // kernel covers hops 0 .. n_hops-2; the last hop and the ragged tail stay on the generic kernels.
-    std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0);
+    std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0), fsp(nt, 0);  // fused K-weighting / + true-peak screen / + sample peak
     for (size_t i = 0; i < nt; i++) {
         const TrackDesc &d = g.descs[i];
         const bool ok = d.role != 1 && ctx->cfg.engine != 1 && d.fmt == HR_FMT_F32 && d.ch == 2 && d.n_hops >= 2 && d.hop >= 64 &&
                         (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
         fkw[i] = ok;
         ftp[i] = ok && do_peaks && ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[d.rate_idx].tp_atab != nullptr;
+        // the peak is the plain sample peak: HR_TP_SAMPLE, 192 kHz input (nothing to interpolate)
+        const bool plain = ctx->cfg.tp_mode == HR_TP_SAMPLE ||
+                           (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[d.rate_idx].swr_phases == 0) ||
+                           (ctx->cfg.tp_mode == HR_TP_BS1770 && d.fs >= 192000);
+        fsp[i] = ok && do_peaks && !ftp[i] && plain;
     }
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
-    // class 6 = K-weight only
-    constexpr int kFusedClasses = 7;
+    // class 6 = K-weight only, class 7 = K-weight + sample peak
+    constexpr int kFusedClasses = 8;
     size_t class_off[kFusedClasses + 1];
     // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
     // mixes rates: every (class, rate) run is padded to a multiple of 4 with n_rows == 0 copies of its last item.
@@ -266,7 +271,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             for (size_t i = 0; i < nt; i++) {
                 if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri)) continue;
                 const RateDev &rd = ctx->rates_h[ri];
-                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) : kFusedClasses - 1;
+                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
                 const uint64_t interior = g.descs[i].n_hops - 1;
                 for (uint64_t h = 0; h < interior; h += 64)
@@ -327,7 +332,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     const bool plain = (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0) ||
                                        (ctx->cfg.tp_mode == HR_TP_BS1770 && g.descs[i].fs >= 192000);
                     if (plain != (kind == 1)) continue;
-                    const uint64_t n0 = ftp[i] ? (g.descs[i].n_hops - 1) * g.descs[i].hop : 0;
+                    const uint64_t n0 = (ftp[i] || fsp[i]) ? (g.descs[i].n_hops - 1) * g.descs[i].hop : 0;
                     // (the tail of a fused track is cut into short items: many brief workgroups beside the fused kernel
                     // instead of one long-running one)
                     const uint32_t span = ftp[i] && kind == 0 && ctx->cfg.tp_mode == HR_TP_SWR192K ? kTailSpan : 0;
@@ -387,10 +392,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             FusedScratch fsc = fs;
             fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
             fsc.cand_cnt = fs.cand_cnt + off;
-            const bool tp = cls < kFusedClasses - 1;
+            const bool tp = cls < 6;
             launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
                               ctx->peaks.as<unsigned long long>(),
-                              tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1), cls, dbg, st);
+                              tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1), cls,
+                              cls == 7 ? (dbg | 64) : dbg, st);
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));

@@ -253,7 +253,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                                                        unsigned *__restrict__ overflow,
                                                        unsigned long long *__restrict__ peaks, int dbg)
 {
-    // dbg (timing experiments only, results are wrong when set): 1 = never list candidates,
+    // dbg bit 6 (64, a production switch of the K-weighting-only build): also track the sample peak of the frames read
+    // (HR_TP_SAMPLE, and 192 kHz input whose "true peak" is the sample peak)
+    // other dbg bits (timing experiments only, results are wrong when set): 1 = never list candidates,
     // 16 = no PCM / carry-table DMA after the first piece
     extern __shared__ __attribute__((aligned(16))) char smem[];  // kGroupLds
     const int lane = threadIdx.x & 63;
@@ -453,6 +455,15 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         }
         // fragments of piece k go into slot k mod 3
         make_frags(slot_c);
+        if constexpr (!DO_TP) {
+            if (dbg & 64) {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
+                    s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
+                }
+            }
+        }
 
         if constexpr (DO_TP) {
             // Bounds, per channel.  S_u >= every |x| of the window (it includes piece k) so err bounds
@@ -698,6 +709,17 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             o.e0 = ks[c].e0;
             o.q[0] = ks[c].q0; o.q[1] = ks[c].q1; o.q[2] = ks[c].q2; o.q[3] = ks[c].q3;
             o.s[0] = ks[c].y1; o.s[1] = ks[c].y1 - ks[c].y2; o.s[2] = ks[c].z1; o.s[3] = ks[c].z1 - ks[c].z2;
+        }
+    }
+    if constexpr (!DO_TP) {
+        if (dbg & 64) {  // every value seen is a frame of this track (or a reflected copy of one): an exact partial maximum
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const float Sf = wave_max_f32(s_lane[c]);
+                if (lane == 0 && Sf > 0.0f)
+                    atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
+                              static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(Sf))));
+            }
         }
     }
     if constexpr (DO_TP) {
