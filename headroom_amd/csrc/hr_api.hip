@@ -74,7 +74,7 @@ struct hr_ctx {
     std::vector<uint32_t> rate_fs;
     std::vector<RateDev> rates_h;
     std::vector<void *> rate_allocs;
-    DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, bs_taps, unit_tap;
+    DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, unit_tap;
 
     // workspace (grow-only)
     DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
@@ -134,9 +134,6 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     std::memcpy(rd.M1, rt->M[0], sizeof rd.M1);
     std::memcpy(rd.M2, rt->M[1], sizeof rd.M2);
     rd.hop = rt->hop;
-    rd.swr_phases = rt->swr_phases;
-    rd.swr_step = rt->swr_step;
-    rd.swr_l1 = rt->swr_l1;
     rd.q_n0 = rt->q_n0;
     std::memcpy(rd.q_ab, rt->q_ab, sizeof rd.q_ab);
     void *g = nullptr;
@@ -145,22 +142,30 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     HIPCHK(hipMemset(g, 0, rt->g.size() * sizeof(double) + 2048));
     HIPCHK(hipMemcpy(g, rt->g.data(), rt->g.size() * sizeof(double), hipMemcpyHostToDevice));
     rd.g = static_cast<const double *>(g);
-    if (rt->swr_phases > 0) {
-        void *tp = nullptr, *tp32 = nullptr;
-        HIPCHK(hipMalloc(&tp, rt->swr_taps.size() * sizeof(double)));
+    // the interpolation bank of the context's true-peak mode
+    const bool bs = ctx->cfg.tp_mode == HR_TP_BS1770;
+    const int phases = bs ? rt->bs_phases : rt->swr_phases;
+    const std::vector<double> &taps = bs ? rt->bs_taps : rt->swr_taps;
+    const std::vector<uint16_t> &atab = bs ? rt->bs_atab : rt->tp_atab;
+    rd.swr_phases = phases;
+    rd.swr_step = bs ? rt->bs_step : rt->swr_step;
+    rd.swr_l1 = bs ? rt->bs_l1 : rt->swr_l1;
+    rd.tp_passthru0 = bs ? 0 : 1;
+    if (phases > 0) {
+        void *tp = nullptr;
+        HIPCHK(hipMalloc(&tp, taps.size() * sizeof(double)));
         ctx->rate_allocs.push_back(tp);
-        HIPCHK(hipMemcpy(tp, rt->swr_taps.data(), rt->swr_taps.size() * sizeof(double), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(tp, taps.data(), taps.size() * sizeof(double), hipMemcpyHostToDevice));
         rd.swr_taps = static_cast<const double *>(tp);
-        (void)tp32;
-        if (!rt->tp_atab.empty()) {
+        if (!atab.empty()) {
             void *at = nullptr;
-            HIPCHK(hipMalloc(&at, rt->tp_atab.size() * sizeof(uint16_t)));
+            HIPCHK(hipMalloc(&at, atab.size() * sizeof(uint16_t)));
             ctx->rate_allocs.push_back(at);
-            HIPCHK(hipMemcpy(at, rt->tp_atab.data(), rt->tp_atab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
+            HIPCHK(hipMemcpy(at, atab.data(), atab.size() * sizeof(uint16_t), hipMemcpyHostToDevice));
             rd.tp_atab = at;
-            rd.tp_np = rt->tp_np;
-            rd.tp_mt = rt->tp_mt;
-            rd.tp_last_rows = rt->tp_max_out - 32 * (rt->tp_mt - 1);
+            rd.tp_np = bs ? rt->bs_np : rt->tp_np;
+            rd.tp_mt = bs ? rt->bs_mt : rt->tp_mt;
+            rd.tp_last_rows = (bs ? rt->bs_max_out : rt->tp_max_out) - 32 * (rd.tp_mt - 1);
         }
     }
     ctx->rate_fs.push_back(fs);
@@ -207,6 +212,8 @@ void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bo
     d.stream_start = stream_start;
     d.stream_end = stream_end;
     d.tp_enabled = tp_mode != HR_TP_SWR192K || stream_frames >= kSwrTaps + 1;
+    d.tp_reflect = tp_mode == HR_TP_SWR192K;
+    d.tp_drop = tp_mode == HR_TP_SWR192K ? 16 : 0;
     d.blk_first = has_left ? -kPreHop : 0;
     const int64_t hops_avail = static_cast<int64_t>(d.n_hops) + (has_left ? kPreHop : 0);
     d.n_blocks = hops_avail >= 4 ? static_cast<uint64_t>(hops_avail - 3) : 0;
@@ -249,11 +256,10 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         const bool ok = d.role != 1 && ctx->cfg.engine != 1 && d.fmt == HR_FMT_F32 && d.ch == 2 && d.n_hops >= 2 && d.hop >= 64 &&
                         (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
         fkw[i] = ok;
-        ftp[i] = ok && do_peaks && ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[d.rate_idx].tp_atab != nullptr;
+        ftp[i] = ok && do_peaks && (ctx->cfg.tp_mode == HR_TP_SWR192K || ctx->cfg.tp_mode == HR_TP_BS1770) &&
+                 ctx->rates_h[d.rate_idx].tp_atab != nullptr;
         // the peak is the plain sample peak: HR_TP_SAMPLE, 192 kHz input (nothing to interpolate)
-        const bool plain = ctx->cfg.tp_mode == HR_TP_SAMPLE ||
-                           (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[d.rate_idx].swr_phases == 0) ||
-                           (ctx->cfg.tp_mode == HR_TP_BS1770 && d.fs >= 192000);
+        const bool plain = ctx->cfg.tp_mode == HR_TP_SAMPLE || ctx->rates_h[d.rate_idx].swr_phases == 0;
         fsp[i] = ok && do_peaks && !ftp[i] && plain;
     }
     std::vector<FusedItem> &fitems = ctx->h_fitems;
@@ -329,13 +335,12 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             if (do_peaks)
                 for (size_t i = 0; i < nt; i++) {
                     if (g.fmts[i] != f || g.descs[i].role == 1) continue;
-                    const bool plain = (ctx->cfg.tp_mode == HR_TP_SWR192K && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0) ||
-                                       (ctx->cfg.tp_mode == HR_TP_BS1770 && g.descs[i].fs >= 192000);
+                    const bool plain = ctx->cfg.tp_mode != HR_TP_SAMPLE && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0;
                     if (plain != (kind == 1)) continue;
                     const uint64_t n0 = (ftp[i] || fsp[i]) ? (g.descs[i].n_hops - 1) * g.descs[i].hop : 0;
                     // (the tail of a fused track is cut into short items: many brief workgroups beside the fused kernel
                     // instead of one long-running one)
-                    const uint32_t span = ftp[i] && kind == 0 && ctx->cfg.tp_mode == HR_TP_SWR192K ? kTailSpan : 0;
+                    const uint32_t span = ftp[i] && kind == 0 ? kTailSpan : 0;
                     for (uint64_t n = n0; n < g.descs[i].frames; n += span ? span : kPeakSpan)
                         items.push_back({static_cast<uint32_t>(i), span, n});
                 }
@@ -375,7 +380,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         for (int f = 0; f < 5; f++)
             for (int kind = 0; kind < 2; kind++) {
                 if (!pk_span[f][kind].n) continue;
-                launch_true_peak_generic(f, kind == 1 ? HR_TP_SAMPLE : ctx->cfg.tp_mode, dt, dr, ctx->bs_taps.as<double>(),
+                // (both interpolators are banks of the same shape: one kernel, the context's bank in the rate tables)
+                launch_true_peak_generic(f, kind == 1 || ctx->cfg.tp_mode == HR_TP_SAMPLE ? HR_TP_SAMPLE : HR_TP_SWR192K, dt, dr,
                                          di + pk_span[f][kind].off, static_cast<uint32_t>(pk_span[f][kind].n), kPeakSpan,
                                          ctx->peaks.as<unsigned long long>(), tail_st);
             }
@@ -539,7 +545,7 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     int rc = upload(ctx->ovf_items, items.data(), items.size() * sizeof(WorkItem), st);
     if (rc) return rc;
     launch_true_peak_generic(HR_FMT_F32, HR_TP_SWR192K, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(),
-                             ctx->bs_taps.as<double>(), ctx->ovf_items.as<WorkItem>(), static_cast<uint32_t>(items.size()),
+                             ctx->ovf_items.as<WorkItem>(), static_cast<uint32_t>(items.size()),
                              kPeakSpan, ctx->peaks.as<unsigned long long>(), st);
     HIPCHK(hipGetLastError());
     return HR_OK;
@@ -693,7 +699,6 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     int rc = upload(ctx->ebu_energy, ebur128_bin_energy().data(), kEbuBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_energy, loudnorm_bin_energy().data(), kLnBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_bounds, loudnorm_bin_bounds().data(), (kLnBins + 1) * sizeof(double), ctx->stream);
-    if (!rc) rc = upload(ctx->bs_taps, bs1770_taps(), 48 * sizeof(double), ctx->stream);
     double unit[kSwrTaps] = {0};
     unit[15] = 1.0;  // the centre tap: a one-phase "bank" that passes 192 kHz input through
     if (!rc) rc = upload(ctx->unit_tap, unit, sizeof unit, ctx->stream);
@@ -708,7 +713,7 @@ void hr_destroy(hr_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->bs_taps, &ctx->unit_tap, &ctx->tracks_d,
+    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
                       &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();

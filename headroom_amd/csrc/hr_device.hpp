@@ -38,6 +38,11 @@ struct RateDev {
     uint32_t hop;
     int32_t swr_phases, swr_step;
     double swr_l1;
+    // The bank above is libswresample's (HR_TP_SWR192K) or the BS.1770 Annex 2 oversampler in the same shape
+    // (HR_TP_BS1770), chosen when the context builds its tables.  tp_passthru0: phase 0 is a unit impulse (swr), so
+    // its outputs are the samples themselves and the sample peak is a lower bound of the true peak.
+    int32_t tp_passthru0;
+    int32_t pad_;
 };
 
 // zero-state record of one (hop, channel)
@@ -63,7 +68,10 @@ struct TrackDesc {
     uint16_t ch, fmt;
     uint8_t stream_start;  // frame 0 is the start of the stream (swr start reflection / zero history)
     uint8_t stream_end;    // last frame is the end of the stream (no resampler flush: last 16 positions dropped)
-    uint8_t tp_enabled;    // resampler produces output at all (stream >= 33 frames)
+    uint8_t tp_enabled;    // resampler produces output at all (swr: stream >= 33 frames)
+    uint8_t tp_reflect;    // frames in front of the stream are its mirror image (libswresample) instead of silence
+    uint8_t tp_drop;       // positions at the stream end that produce no output (swr: 16, no flush; BS.1770: 0)
+    uint8_t pad2_;
     uint8_t role;          // 0 ordinary track; 1 parent of stereo planes (measured through them: no work items of its
                            // own, only hop-sum slots and gating); 2 stereo plane of a parent
     uint32_t first_plane;  // role 1: index of the first of its (ch+1)/2 consecutive plane descriptors

@@ -33,10 +33,10 @@ void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint
 // libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases/step) interleaved f64 frames
 void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, const double *taps,
                          double *dst, hipStream_t st);
-// tp_kind: 0 swr192k, 1 bs1770, 2 sample peak; every item covers `span` (multiple of 256) positions, or item.pad
-// positions when that is non-zero (swr192k only)
+// tp_kind: 0 = the context's interpolation bank (libswresample's or BS.1770's, RateDev), 2 = sample peak; every item
+// covers `span` (multiple of 256) positions, or item.pad positions when that is non-zero (bank kernel only)
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
-                              const double *bs_taps, const WorkItem *items, uint32_t n_items, uint32_t span,
+                              const WorkItem *items, uint32_t n_items, uint32_t span,
                               unsigned long long *peaks, hipStream_t st);
 
 // hr_kernels_fused.hip: stereo f32, swr true peak.  variant 0 = full; 1 = K-weight only, 2 = true peak only,

@@ -111,6 +111,7 @@ __device__ __forceinline__ double fetch_f32s(const TrackDesc &t, int c, int64_t 
     const int64_t N = static_cast<int64_t>(t.frames);
     if (i < 0) {
         if (t.left_tail) return (i >= -kHalo) ? t.left_tail[(kHalo + i) * 2 + c] : 0.0;
+        if (!t.tp_reflect) return 0.0;  // BS.1770: silence in front of the stream
         i = -i;
     }
     if (i >= N) {
@@ -266,6 +267,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const FusedItem it = items[item_idx];
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
+    const bool passthru0 = r.tp_passthru0 != 0;  // else (BS.1770 bank) the sample peak bounds nothing and phase 0 is screened
     const KCoef kc = r.k;
     const uint32_t hop = t.hop;
     const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
@@ -320,7 +322,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                                    static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 1]));
             ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
             ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
-        } else {
+        } else if (t.tp_reflect) {
             // start of the stream: libswresample reflects, x[-j] = x[j]; the K-weighting starts from silence
 #pragma unroll
             for (int c = 0; c < 8; c++) {
@@ -328,6 +330,10 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 const float2 b = *reinterpret_cast<const float2 *>(rowp + 2 * (15 - 2 * c));
                 v[c] = make_float4(a.x, a.y, b.x, b.y);
             }
+        } else {
+            // BS.1770: silence in front of the stream
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
 
@@ -355,6 +361,19 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     unsigned n_cand = 0;             // wave-uniform: candidates appended so far
     uint2 *__restrict__ my_cands = cands + static_cast<size_t>(item_idx) * kCandCap;
 
+    // wave-wide bounds and this lane's candidate thresholds from the per-lane maxima seen so far
+    auto refresh_bounds = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            S_u[ch] = wave_max_f32(s_lane[ch]);
+            A_u[ch] = wave_max_f32(alb[ch]);
+            const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
+            lb[ch] = fmaxf(lb[ch], fmaxf(passthru0 ? S_u[ch] : 0.0f, A_u[ch] - err));
+            const float thr = fmaxf(lb[ch] - err, 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
+            thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
+            thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
+        }
+    };
     auto make_frags = [&](auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
 #ifdef HR_EXP_NO_FRAGS
@@ -473,18 +492,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             // (one compare: a VALU compare that feeds a scalar branch costs as much as half a dozen f32 operations)
             const float over = fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1]));
             const bool stale = over > 0.0f;
-            if (__ballot(stale) != 0ull) {
-#pragma unroll
-                for (int ch = 0; ch < 2; ch++) {
-                    S_u[ch] = wave_max_f32(s_lane[ch]);
-                    A_u[ch] = wave_max_f32(alb[ch]);
-                    const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
-                    lb[ch] = fmaxf(lb[ch], fmaxf(S_u[ch], A_u[ch] - err));
-                    const float thr = fmaxf(lb[ch] - err, 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
-                    thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
-                    thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
-                }
-            }
+            if (__ballot(stale) != 0ull) refresh_bounds();
         }
 
         // ---- the hot block, branch-free so that the scheduler can run the f64 K-weighting of piece k under
@@ -639,6 +647,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             screen();
         }
         if constexpr (DO_TP) {
+            // Without a pass-through phase nothing bounds the peak from below until a tile has been screened: the
+            // first tile with signal refreshes the bounds BEFORE its groups are listed (else every group would be one).
+            if (!passthru0 && (lb[0] == 0.0f || lb[1] == 0.0f)) refresh_bounds();
             // groups that can still hold the maximum go on the wave's list (columns past n_rows have an infinite
             // threshold; step 0 screens zeros against an infinite threshold)
             float margin = -__builtin_inff();  // max over the lane's groups of (group maximum - its threshold)
@@ -729,7 +740,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         for (int c = 0; c < 2; c++) {
             Sf[c] = wave_max_f32(s_lane[c]);
             Af[c] = wave_max_f32(alb[c]);
-            lb[c] = fmaxf(lb[c], fmaxf(Sf[c], Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
+            lb[c] = fmaxf(lb[c], fmaxf(passthru0 ? Sf[c] : 0.0f, Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
         }
         if (lane == 0) {
             cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
@@ -740,7 +751,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(lb[c]));
                 atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(Sf[c]));
                 // phase-0 outputs are the samples themselves: exact, and not part of the screen
-                if (Sf[c] > 0.0f)
+                if (passthru0 && Sf[c] > 0.0f)
                     atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
                               static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(Sf[c]))));
             }
@@ -785,6 +796,7 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
     const FusedItem it = items[item_idx];
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
+    const bool passthru0 = r.tp_passthru0 != 0;
     const uint32_t hop = t.hop;
     const int T = static_cast<int>((hop + 15) / 16);
     const int n_rows = static_cast<int>(it.n_rows);
@@ -851,13 +863,16 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
             for (int c = 0; c < 8; c++)
                 v[c] = make_float4(static_cast<float>(t.left_tail[(2 * c) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c) * 2 + 1]),
                                    static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 0]), static_cast<float>(t.left_tail[(2 * c + 1) * 2 + 1]));
-        } else {
+        } else if (t.tp_reflect) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 const float2 a = *reinterpret_cast<const float2 *>(rowp + 2 * (16 - 2 * c));
                 const float2 b = *reinterpret_cast<const float2 *>(rowp + 2 * (15 - 2 * c));
                 v[c] = make_float4(a.x, a.y, b.x, b.y);
             }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
     const bool have_history = h > 0 || t.left_tail;  // else: start of the stream, the K-weighting starts from silence
@@ -987,6 +1002,19 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
     unsigned n_cand = 0;
     uint2 *__restrict__ my_cands = cands + static_cast<size_t>(item_idx) * kCandCap;
 
+    // wave-wide bounds and this lane's candidate thresholds from the per-lane maxima seen so far
+    auto refresh_bounds = [&]() {
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++) {
+            S_u[ch] = wave_max_f32(s_lane[ch]);
+            A_u[ch] = wave_max_f32(alb[ch]);
+            const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
+            lb[ch] = fmaxf(lb[ch], fmaxf(passthru0 ? S_u[ch] : 0.0f, A_u[ch] - err));
+            const float thr = fmaxf(lb[ch] - err, 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
+            thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
+            thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
+        }
+    };
     auto make_frags = [&](auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
 #pragma unroll
@@ -1042,18 +1070,7 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
         {
             const float over = fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1]));
             const bool stale = over > 0.0f;
-            if (__ballot(stale) != 0ull) {
-#pragma unroll
-                for (int ch = 0; ch < 2; ch++) {
-                    S_u[ch] = wave_max_f32(s_lane[ch]);
-                    A_u[ch] = wave_max_f32(alb[ch]);
-                    const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
-                    lb[ch] = fmaxf(lb[ch], fmaxf(S_u[ch], A_u[ch] - err));
-                    const float thr = fmaxf(lb[ch] - err, 1e-30f);
-                    thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
-                    thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
-                }
-            }
+            if (__ballot(stale) != 0ull) refresh_bounds();
         }
         // screen of tile k-1 (pieces k-2, k-1, k)
         float m0[MT][2][2];
@@ -1094,6 +1111,7 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
                 }
             }
         }
+        if (!passthru0 && (lb[0] == 0.0f || lb[1] == 0.0f)) refresh_bounds();  // (see k_fused_f32s)
         float margin = -__builtin_inff();
 #pragma unroll
         for (int ch = 0; ch < 2; ch++)
@@ -1137,7 +1155,7 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
         for (int c = 0; c < 2; c++) {
             Sf[c] = wave_max_f32(s_lane[c]);
             Af[c] = wave_max_f32(alb[c]);
-            lb[c] = fmaxf(lb[c], fmaxf(Sf[c], Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
+            lb[c] = fmaxf(lb[c], fmaxf(passthru0 ? Sf[c] : 0.0f, Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
         }
         if (lane == 0) {
             cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
@@ -1146,7 +1164,7 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
             for (int c = 0; c < 2; c++) {
                 atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(lb[c]));
                 atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(Sf[c]));
-                if (Sf[c] > 0.0f)
+                if (passthru0 && Sf[c] > 0.0f)
                     atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
                               static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(Sf[c]))));
             }
@@ -1186,7 +1204,7 @@ __global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__re
         const int rowidx = 32 * mt + 4 * half + (i & 3) + 8 * (i >> 2);
         if (rowidx >= count) continue;
         const int m = m_lo + rowidx;
-        if ((m * step) % P == 0) continue;  // pass-through phase: taken exactly from the sample peak
+        if (r.tp_passthru0 && (m * step) % P == 0) continue;  // pass-through phase: taken exactly from the sample peak
         const double a = exact_output(t, r.swr_taps, P, step, row_frame0, ch, m);
         best = a > best ? a : best;
     }

@@ -660,7 +660,7 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
     const int64_t N = static_cast<int64_t>(t.frames);
     const int P = r.swr_phases, step = r.swr_step;
     // an output at position pos needs frames pos-15 .. pos+16
-    const int64_t last_pos = t.stream_end ? N - 17 : N - 1;
+    const int64_t last_pos = t.stream_end ? N - 1 - t.tp_drop : N - 1;
     const int C = t.ch;
     for (int c = 0; c < C; c++) {
         double m = 0.0;
@@ -669,7 +669,7 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
             if (!(t.tp_enabled && pos <= last_pos && pos < N)) continue;
             double x[kSwrTaps];
 #pragma unroll
-            for (int i = 0; i < kSwrTaps; i++) x[i] = fetch<FMT>(t, c, pos - 15 + i, true);
+            for (int i = 0; i < kSwrTaps; i++) x[i] = fetch<FMT>(t, c, pos - 15 + i, t.tp_reflect != 0);
             // outputs n with floor(n*step/P) == pos
             const int64_t n_lo = (pos * P + step - 1) / step;
             const int64_t n_hi = ((pos + 1) * P + step - 1) / step;
@@ -728,37 +728,6 @@ void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels
 #define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, taps, dst); break;
     switch (fmt) { HR_RS_CASE(0) HR_RS_CASE(1) HR_RS_CASE(2) HR_RS_CASE(3) default: HR_RS_CASE(4) }
 #undef HR_RS_CASE
-}
-
-template <int FMT>
-__global__ void __launch_bounds__(256) k_true_peak_bs1770(const TrackDesc *__restrict__ tracks,
-                                                          const double *__restrict__ taps /*[4][12]*/,
-                                                          const WorkItem *__restrict__ items, uint32_t span,
-                                                          unsigned long long *__restrict__ peaks)
-{
-    const WorkItem it = items[blockIdx.x];
-    const TrackDesc &t = tracks[it.track];
-    const int64_t N = static_cast<int64_t>(t.frames);
-    const int stride = t.fs < 96000 ? 1 : 2;  // x4 below 96 kHz, x2 below 192 kHz
-    const int C = t.ch;
-    for (int c = 0; c < C; c++) {
-        double m = 0.0;
-        for (uint32_t off = 0; off < span; off += 256) {
-            const int64_t n = static_cast<int64_t>(it.first) + off + threadIdx.x;
-            if (n >= N) continue;
-            double x[12];
-#pragma unroll
-            for (int k = 0; k < 12; k++) x[k] = fetch<FMT>(t, c, n - k, false);
-            for (int p = 0; p < 4; p += stride) {
-                double val = 0.0;
-#pragma unroll
-                for (int k = 0; k < 12; k++) val = fma(x[k], taps[p * 12 + k], val);
-                const double a = fabs(val);
-                m = a > m ? a : m;
-            }
-        }
-        peak_commit(m, &peaks[static_cast<size_t>(it.track) * kMaxCh + c]);
-    }
 }
 
 template <int FMT>
@@ -852,14 +821,12 @@ void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode
 }
 
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
-                              const double *bs_taps, const WorkItem *items, uint32_t n_items, uint32_t span,
+                              const WorkItem *items, uint32_t n_items, uint32_t span,
                               unsigned long long *peaks, hipStream_t st)
 {
     if (!n_items) return;
     if (tp_kind == 0) {
         HR_FMT_DISPATCH(fmt, (k_true_peak_swr<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, rates, items, span, peaks)));
-    } else if (tp_kind == 1) {
-        HR_FMT_DISPATCH(fmt, (k_true_peak_bs1770<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, bs_taps, items, span, peaks)));
     } else {
         HR_FMT_DISPATCH(fmt, (k_sample_peak<F><<<dim3(n_items), dim3(256), 0, st>>>(tracks, items, span, peaks)));
     }

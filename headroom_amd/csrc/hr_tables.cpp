@@ -130,9 +130,10 @@ uint16_t f32_to_f16_rn(float f)
     return static_cast<uint16_t>(sign | m);
 }
 
-static void build_tp_tiles(RateTables &rt)
+// passthru0: phase 0 of the bank is a unit impulse whose outputs the kernel takes from the sample peak
+static void build_tp_tiles(int P, int step, const std::vector<double> &taps, bool passthru0, std::vector<uint16_t> &atab,
+                           int &tp_np, int &tp_mt, int &tp_max_out)
 {
-    const int P = rt.swr_phases, step = rt.swr_step;
     if (P <= 0) return;
     int g = 16, b = step;
     while (b) { const int tmp = g % b; g = b; b = tmp; }
@@ -143,10 +144,10 @@ static void build_tp_tiles(RateTables &rt)
         max_out = std::max(max_out, (16L * (p + 1) * P + step - 1) / step - (16L * p * P + step - 1) / step);
     const int MT = static_cast<int>((max_out + 31) / 32);
     if (MT > 3) return;  // low sample rates (many phases per input frame) stay on the generic kernel
-    rt.tp_np = NP;
-    rt.tp_mt = MT;
-    rt.tp_max_out = static_cast<int>(max_out);
-    rt.tp_atab.assign(static_cast<size_t>(NP) * MT * 3 * 64 * 8, 0);
+    tp_np = NP;
+    tp_mt = MT;
+    tp_max_out = static_cast<int>(max_out);
+    atab.assign(static_cast<size_t>(NP) * MT * 3 * 64 * 8, 0);
     for (int p = 0; p < NP; p++) {
         const long m_lo = (16L * p * P + step - 1) / step;
         const long m_hi = (16L * (p + 1) * P + step - 1) / step;
@@ -163,11 +164,30 @@ static void build_tp_tiles(RateTables &rt)
                             const int tap = kappa - 1 - static_cast<int>(u);  // output uses frames pos-15 .. pos+16
                             // phase 0 is a unit impulse (the output IS the input sample): the kernel takes those
                             // outputs exactly from the sample peak, so their rows stay zero and are never candidates
-                            if (ph != 0 && tap >= 0 && tap < kSwrTaps) v = rt.swr_taps[static_cast<size_t>(ph) * kSwrTaps + tap];
+                            if ((ph != 0 || !passthru0) && tap >= 0 && tap < kSwrTaps) v = taps[static_cast<size_t>(ph) * kSwrTaps + tap];
                         }
-                        rt.tp_atab[((((static_cast<size_t>(p) * MT + mt) * 3 + ks) * 64) + lane) * 8 + i] =
+                        atab[((((static_cast<size_t>(p) * MT + mt) * 3 + ks) * 64) + lane) * 8 + i] =
                             f32_to_f16_rn(static_cast<float>(v));
                     }
+    }
+}
+
+static void build_bs1770(RateTables &rt)
+{
+    const int P = rt.fs < 96000 ? 4 : (rt.fs < 192000 ? 2 : 0);
+    if (!P) return;
+    rt.bs_phases = P;
+    rt.bs_step = 1;
+    rt.bs_taps.assign(static_cast<size_t>(P + 1) * kSwrTaps, 0.0);
+    const double *h = bs1770_taps();
+    for (int ph = 0; ph < P; ph++) {
+        const int src = ph * (4 / P);
+        double l1 = 0;
+        for (int k = 0; k < 12; k++) {
+            rt.bs_taps[static_cast<size_t>(ph) * kSwrTaps + 15 - k] = h[src * 12 + k];
+            l1 += std::fabs(h[src * 12 + k]);
+        }
+        if (l1 > rt.bs_l1) rt.bs_l1 = l1;
     }
 }
 
@@ -272,7 +292,9 @@ const RateTables *rate_tables(uint32_t fs)
     rt->k = kweight_coeffs(static_cast<double>(fs));
     build_carry(*rt);
     build_swr(*rt);
-    build_tp_tiles(*rt);
+    build_tp_tiles(rt->swr_phases, rt->swr_step, rt->swr_taps, true, rt->tp_atab, rt->tp_np, rt->tp_mt, rt->tp_max_out);
+    build_bs1770(*rt);
+    build_tp_tiles(rt->bs_phases, rt->bs_step, rt->bs_taps, false, rt->bs_atab, rt->bs_np, rt->bs_mt, rt->bs_max_out);
     const RateTables *p = rt.get();
     cache[fs] = std::move(rt);
     return p;

@@ -49,6 +49,15 @@ struct RateTables {
     std::vector<uint16_t> tp_atab;
     int tp_np = 0, tp_mt = 0;
     int tp_max_out = 0;  // most outputs any tile has
+    // ITU-R BS.1770-4 Annex 2 oversampler written as a bank of the same shape, so that the same kernels serve it:
+    // bs_phases = 4 below 96 kHz, 2 below 192 kHz (phases 0 and 2 of the table), 0 at and above (sample peak);
+    // bs_step = 1; output n*P + p = sum_k x[n-k]*h[p][k] sits in tap slot 15-k of phase p (slots 16..31 are zero: the
+    // filter is causal).  Phase 0 of this bank is a real filter, not a pass-through.
+    int bs_phases = 0, bs_step = 0;
+    std::vector<double> bs_taps;   // [(phases+1)][32]
+    double bs_l1 = 0;
+    std::vector<uint16_t> bs_atab;
+    int bs_np = 0, bs_mt = 0, bs_max_out = 0;
 };
 
 // Builds (and caches per process) the tables of one rate.  Returns nullptr for fs < 10.

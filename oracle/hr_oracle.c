@@ -610,7 +610,8 @@ static void true_peak_bs1770(const hro_track *t, double *peak)
             }
             for (int p = 0; p < 4; p += 4 / factor) {
                 double val = 0.0;
-                for (int k = 0; k < 12; k++) {
+                for (int k = 11; k >= 0; k--) { /* oldest sample first (the order is not part of the spec; the GPU's
+                                                    bank form of this filter sums in this order) */
                     const int64_t i = n - k;
                     const double x = i >= 0 ? hro_sample(t->pcm, t->fmt, (uint64_t)i * C + c) : 0.0;
                     val = fma(x, bs1770_taps[p][k], val);

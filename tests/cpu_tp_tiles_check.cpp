@@ -1,7 +1,7 @@
 // Test-only host check of the f16 coefficient tiles of the MFMA true-peak screen (hr_tables.cpp
 // build_tp_tiles): for random data, (tile x window) must reproduce every interpolated output of the tile
 // within the screen's error bound, and f32_to_f16_rn must round like IEEE binary16.
-//   usage: cpu_tp_tiles_check <fs>
+//   usage: cpu_tp_tiles_check <fs> [bs]     (bs: the BS.1770 Annex 2 bank instead of libswresample's)
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -46,8 +46,12 @@ int main(int argc, char **argv)
         }
     }
     const hr::RateTables *rt = hr::rate_tables(fs);
-    if (rt->tp_atab.empty()) { std::printf("no tiles for %u\n", fs); return 0; }
-    const int P = rt->swr_phases, step = rt->swr_step, NP = rt->tp_np, MT = rt->tp_mt;
+    const bool bs = argc > 2 && !std::strcmp(argv[2], "bs");
+    const std::vector<uint16_t> &atab = bs ? rt->bs_atab : rt->tp_atab;
+    const std::vector<double> &taps = bs ? rt->bs_taps : rt->swr_taps;
+    if (atab.empty()) { std::printf("no tiles for %u\n", fs); return 0; }
+    const int P = bs ? rt->bs_phases : rt->swr_phases, step = bs ? rt->bs_step : rt->swr_step;
+    const int NP = bs ? rt->bs_np : rt->tp_np, MT = bs ? rt->bs_mt : rt->tp_mt;
     const uint32_t hop = rt->hop;
     const int T = (hop + 15) / 16;
     // a "row": hop frames plus 16 before and 48 after
@@ -79,7 +83,7 @@ int main(int argc, char **argv)
             for (int kappa = 0; kappa < 48; kappa++) {
                 const int k3 = kappa / 16, half = (kappa % 16) / 8, i = kappa % 8;
                 const int lane = (row & 31) + 32 * half;
-                const uint16_t a = rt->tp_atab[((((static_cast<size_t>(pat) * MT + mt) * 3 + k3) * 64) + lane) * 8 + i];
+                const uint16_t a = atab[((((static_cast<size_t>(pat) * MT + mt) * 3 + k3) * 64) + lane) * 8 + i];
                 const float xv = h2f(f2h_rtz(X(16L * t - 16 + kappa)));
                 approx += static_cast<double>(h2f(a)) * xv;
             }
@@ -91,12 +95,12 @@ int main(int argc, char **argv)
             const long u = m * step / P;
             const int ph = static_cast<int>(m * step % P);
             if (u < 16L * t || u >= 16L * t + 16) { std::printf("tile %d row %d: position %ld outside tile\n", t, row, u); return 1; }
-            if (ph == 0) {  // pass-through outputs are not screened (taken exactly from the sample peak)
+            if (ph == 0 && !bs) {  // pass-through outputs are not screened (taken exactly from the sample peak)
                 if (approx != 0) { std::printf("tile %d row %d: phase-0 row is not zero\n", t, row); return 1; }
                 continue;
             }
             double exact = 0;
-            for (int i = 0; i < 32; i++) exact = std::fma(static_cast<double>(X(u - 15 + i)), rt->swr_taps[static_cast<size_t>(ph) * 32 + i], exact);
+            for (int i = 0; i < 32; i++) exact = std::fma(static_cast<double>(X(u - 15 + i)), taps[static_cast<size_t>(ph) * 32 + i], exact);
             worst = std::fmax(worst, std::fabs(exact - approx));
             n_out++;
         }

@@ -144,6 +144,7 @@ def test_tp_screen_tiles_and_error_bound(fs):
     subprocess.check_call(["g++", "-O2", "-std=c++17", "-mfma", os.path.join(ROOT, "tests", "cpu_tp_tiles_check.cpp"),
                            os.path.join(ROOT, "headroom_amd", "csrc", "hr_tables.cpp"), "-o", exe])
     subprocess.check_call([exe, str(fs)], stdout=subprocess.DEVNULL)
+    subprocess.check_call([exe, str(fs), "bs"], stdout=subprocess.DEVNULL)   # the BS.1770 Annex 2 bank
 
 
 # ---- CSV report rows: src/report.rs:29-59 ----------------------------------------------------------------------
