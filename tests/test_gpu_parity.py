@@ -514,3 +514,21 @@ def test_concurrent_callers_share_one_context(oracle, meters):
             assert g["status"] == 0 and g["n_blocks"] == refs[i]["n_blocks"]
             assert abs(g["integrated_lufs"] - refs[i]["integrated_lufs"]) < 1e-6
             assert g["peak_per_ch"] == refs[i]["peak_per_ch"]
+
+
+@pytest.mark.parametrize("tp", ["swr192k", "bs1770"])
+@pytest.mark.parametrize("fs", [8000, 16000, 32000, 64000, 88200, 176400])
+def test_other_sample_rates(oracle, meters, fs, tp):
+    """Rates beside the three of the BASELINE configs: other tile shapes of the fused kernel (32 kHz: three full 32-row
+    blocks; 88.2 kHz: 35 outputs per tile) and, below 32 kHz in the libswresample mode, the generic kernel."""
+    pcm = signals.seeded_noise(900 + fs, int(fs * 3.7) + 13, 2, -11.0)
+    pcm[: fs // 2] *= 0.02
+    check_against_oracle(oracle, meters("ebur128", tp), pcm, fs, "ebur128", tp)
+    x5 = signals.seeded_noise(901 + fs, fs * 2 + 5, 5, -15.0)
+    check_against_oracle(oracle, meters("ebur128", tp), signals.to_s16(x5), fs, "ebur128", tp)
+
+
+def test_bs1770_mode_accepts_rates_libswresample_mode_rejects(oracle, meters):
+    pcm = signals.seeded_noise(77, 22050 * 3, 2, -9.0)
+    check_against_oracle(oracle, meters("ebur128", "bs1770"), pcm, 22050, "ebur128", "bs1770")
+    assert meters().analyze(pcm, 22050)["status"] == hr.ERR_RATE      # 1280 phases: swr would interpolate between phases
