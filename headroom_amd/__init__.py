@@ -46,12 +46,16 @@ class HrResult(C.Structure):
 
 
 class HrShardEdge(C.Structure):
-    _fields_ = [("rec", C.c_double * 9 * MAX_CH * 6), ("tail", C.c_double * MAX_CH * 16), ("n_hops", C.c_uint64)]
+    _fields_ = [("rec", C.c_double * 9 * MAX_CH * 6), ("tail", C.c_double * MAX_CH * 16), ("n_hops", C.c_uint64),
+                ("hop_tail", C.c_double * MAX_CH * 29), ("range_ok", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HrShardPartial(C.Structure):
     _fields_ = [("hist", C.c_uint64 * 8001), ("sum_kept", C.c_double), ("n_kept", C.c_uint64), ("n_blocks", C.c_uint64),
-                ("peak_per_ch", C.c_double * MAX_CH)]
+                ("peak_per_ch", C.c_double * MAX_CH),
+                ("st_hist", C.c_uint64 * 8001), ("st_sum_kept", C.c_double), ("st_n_kept", C.c_uint64),
+                ("n_shortterm", C.c_uint64), ("max_m_power", C.c_double), ("max_s_power", C.c_double),
+                ("range_ok", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HrTpTarget(C.Structure):
@@ -106,7 +110,7 @@ def lib():
                                     C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.hr_shard_head.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double)]
     L.hr_shard_pass1.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
-                                 C.c_int, C.POINTER(HrShardEdge)]
+                                 C.c_int, C.c_uint64, C.POINTER(HrShardEdge)]
     L.hr_shard_pass2.argtypes = [C.c_void_p, C.POINTER(HrShardEdge), C.POINTER(HrShardPartial)]
     L.hr_shard_finish.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.c_int, C.POINTER(HrResult)]
     L.hr_analyze_stream_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(HrTrack), C.POINTER(HrResult)]
@@ -324,12 +328,12 @@ class Meter:
         view.c = HrTrack((t.pcm or 0) + off, 16, t.sample_rate, t.channels, t.fmt, t.ch_weight, t.flags, 0)
         return self.shard_head(view)
 
-    def shard_pass1(self, spec, left_tail, right_head):
+    def shard_pass1(self, spec, left_tail, right_head, first_hop=0):
         edge = HrShardEdge()
         lp = left_tail.ctypes.data_as(C.POINTER(C.c_double)) if left_tail is not None else None
         rp = right_head.ctypes.data_as(C.POINTER(C.c_double)) if right_head is not None else None
         _check(lib().hr_shard_pass1(self._h, C.byref(spec.c), lp, rp, int(left_tail is None), int(right_head is None),
-                                    C.byref(edge)), "hr_shard_pass1")
+                                    int(first_hop), C.byref(edge)), "hr_shard_pass1")
         return edge
 
     def shard_pass2(self, left_edge):

@@ -214,8 +214,8 @@ void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bo
     d.tp_enabled = tp_mode != HR_TP_SWR192K || stream_frames >= kSwrTaps + 1;
     d.tp_reflect = tp_mode == HR_TP_SWR192K;
     d.tp_drop = tp_mode == HR_TP_SWR192K ? 16 : 0;
-    d.blk_first = has_left ? -kPreHop : 0;
-    const int64_t hops_avail = static_cast<int64_t>(d.n_hops) + (has_left ? kPreHop : 0);
+    d.blk_first = has_left ? -kPreBlk : 0;
+    const int64_t hops_avail = static_cast<int64_t>(d.n_hops) + (has_left ? kPreBlk : 0);
     d.n_blocks = hops_avail >= 4 ? static_cast<uint64_t>(hops_avail - 3) : 0;
     d.rec_base = g.rec_slots;
     d.hop_base = g.hop_slots;
@@ -323,7 +323,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     for (size_t i = 0; i < nt; i++) {
         const auto &d = g.descs[i];
         if (d.role == 1) continue;
-        const uint64_t pairs = (d.n_hops + (d.blk_first < 0 ? kPreHop : 0)) * d.ch;
+        const uint64_t pairs = (d.n_hops + (d.blk_first < 0 ? kPreBlk : 0)) * d.ch;
         for (uint64_t p = 0; p < pairs; p += 256) items.push_back({static_cast<uint32_t>(i), 0, p});
     }
     comb_span.n = items.size() - comb_span.off;
@@ -421,14 +421,17 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     return HR_OK;
 }
 
-int run_gating(hr_ctx *ctx, Group &g, bool finalize)
+// finalize: relative gate, gated mean and the range statistics per track; range_parts (time shards): only the chunks'
+// short-term histograms and partial sums, which the caller reduces over the shards
+int run_gating(hr_ctx *ctx, Group &g, bool finalize, bool range_parts = false)
 {
     hipStream_t st = ctx->stream;
     const uint32_t nt = static_cast<uint32_t>(g.descs.size());
     if (!nt) return HR_OK;
     const size_t hist_bytes = static_cast<size_t>(nt) * kEbuBins * sizeof(uint32_t);
     if (!ctx->hist.ensure(hist_bytes) || !ctx->outs.ensure(static_cast<size_t>(nt) * sizeof(TrackOut)) ||
-        !ctx->gate_parts.ensure(static_cast<size_t>(g.part_slots) * sizeof(GatePart)) || (finalize && !ctx->st_hist.ensure(hist_bytes)))
+        !ctx->gate_parts.ensure(static_cast<size_t>(g.part_slots) * sizeof(GatePart)) ||
+        ((finalize || range_parts) && !ctx->st_hist.ensure(hist_bytes)))
         return HR_ERR_OOM;
     // one workgroup per chunk of kGateChunk blocks: a 3-minute track is one chunk, a 10-hour stream 22
     std::vector<WorkItem> &items = ctx->h_gate_items;  // (outlives the asynchronous copy)
@@ -446,11 +449,11 @@ int run_gating(hr_ctx *ctx, Group &g, bool finalize)
     launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
                       ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
                       ctx->gate_parts.as<GatePart>(), !finalize, ctx->outs.as<TrackOut>(), st);
-    if (finalize) {
+    if (finalize || range_parts) {
         HIPCHK(hipMemsetAsync(ctx->st_hist.p, 0, hist_bytes, st));
         launch_range_stats(dt, nt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
                            ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->st_hist.as<uint32_t>(),
-                           ctx->gate_parts.as<GatePart>(), ctx->outs.as<TrackOut>(), st);
+                           ctx->gate_parts.as<GatePart>(), finalize, ctx->outs.as<TrackOut>(), st);
     }
     HIPCHK(hipGetLastError());
     return HR_OK;
@@ -859,7 +862,7 @@ int hr_shard_head(hr_ctx *ctx, const hr_track *shard, double *head)
 }
 
 int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
-                   int is_last, hr_shard_edge *edge)
+                   int is_last, uint64_t first_hop, hr_shard_edge *edge)
 {
     if (!ctx || !shard || !edge) return HR_ERR_INVALID;
     if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
@@ -900,8 +903,11 @@ int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, 
     add_desc(g, *shard, dev, ri, is_first != 0, is_last != 0, !is_first, ~0ull, ctx->cfg.tp_mode);
     g.descs[0].left_tail = is_first ? nullptr : halo_l;
     g.descs[0].right_head = is_last ? nullptr : halo_r;
+    g.descs[0].first_hop = first_hop;
     ctx->last_total_ms = ctx->last_main_ms = 0;
-    int rc = run_measure(ctx, g, true, false);
+    // (the combine of pass 1 is for the hop energies handed to the right neighbour: from hop 3 on they do not depend
+    // on the left edge, which only arrives for pass 2; pass 2 combines again)
+    int rc = run_measure(ctx, g, true, true);
     if (rc) return rc;
     // right edge: last 6 hop records and the last 16 frames
     std::memset(edge, 0, sizeof *edge);
@@ -917,7 +923,15 @@ int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, 
     if (tf)
         HIPCHK(hipMemcpyAsync(raw.data(), static_cast<const char *>(dev) + (shard->frames - tf) * C * fb, tf * C * fb,
                               hipMemcpyDeviceToHost, st));
+    // the energies of the last 29 hops, for the right neighbour's first 3 s windows
+    edge->range_ok = nh >= static_cast<uint64_t>(kPreHop + (is_first ? 0 : kPreBlk));
+    std::vector<double> ht(static_cast<size_t>(kPreHop) * C, 0.0);
+    if (edge->range_ok)
+        HIPCHK(hipMemcpyAsync(ht.data(), ctx->hop_sums.as<double>() + d.hop_base + (kPreHop + nh - kPreHop) * C,
+                              ht.size() * sizeof(double), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    for (int k = 0; k < kPreHop; k++)
+        for (int c = 0; c < C; c++) edge->hop_tail[k][c] = ht[static_cast<size_t>(k) * C + c];
     for (uint64_t k = 0; k < take; k++)
         for (int c = 0; c < C; c++) {
             const HopRec &r = tmp[k * C + c];
@@ -958,15 +972,32 @@ int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *par
         HIPCHK(hipMemcpyAsync(ctx->recs.as<HopRec>() + d.rec_base, pre.data(), pre.size() * sizeof(HopRec),
                               hipMemcpyHostToDevice, st));
     }
+    // the left neighbour's last 29 hop energies go in front of hop 0 (the combine below rewrites the last three of them
+    // from the records, to the same values): the 3 s windows that end in this shard are then all its own
+    const bool range_ok = !left || left->range_ok;
+    if (left && left->range_ok) {
+        std::vector<double> ht(static_cast<size_t>(kPreHop) * C);
+        for (int k = 0; k < kPreHop; k++)
+            for (int c = 0; c < C; c++) ht[static_cast<size_t>(k) * C + c] = left->hop_tail[k][c];
+        HIPCHK(hipMemcpyAsync(ctx->hop_sums.as<double>() + d.hop_base, ht.data(), ht.size() * sizeof(double), hipMemcpyHostToDevice, st));
+        HIPCHK(hipStreamSynchronize(st));  // `ht` is a local
+        d.st_pre = kPreHop;
+    }
+    int rc = upload(ctx->tracks_d, g.descs.data(), g.descs.size() * sizeof(TrackDesc), st);  // (st_pre may have changed)
+    if (rc) return rc;
     launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->items_d.as<WorkItem>() + ctx->comb_off,
                        static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), st);
-    int rc = run_gating(ctx, g, false);
+    rc = run_gating(ctx, g, false, true);
     if (rc) return rc;
     rc = redo_overflowed_peaks(ctx, g);
     if (rc) return rc;
-    std::vector<uint32_t> hist(kEbuBins);
+    std::vector<uint32_t> hist(kEbuBins), st_hist(kEbuBins);
+    std::vector<GatePart> parts(d.n_parts);
     TrackOut o{};
     unsigned long long pk[kMaxCh];
+    HIPCHK(hipMemcpyAsync(st_hist.data(), ctx->st_hist.p, kEbuBins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(parts.data(), ctx->gate_parts.as<GatePart>() + d.part_base, parts.size() * sizeof(GatePart),
+                          hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hist.data(), ctx->hist.p, kEbuBins * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pk, ctx->peaks.p, sizeof pk, hipMemcpyDeviceToHost, st));
@@ -978,6 +1009,15 @@ int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *par
     partial->n_kept = o.n_kept;
     partial->n_blocks = o.n_blocks;
     for (int c = 0; c < C; c++) std::memcpy(&partial->peak_per_ch[c], &pk[c], sizeof(double));
+    for (int i = 0; i < nb; i++) partial->st_hist[i] = st_hist[i];
+    for (const GatePart &p : parts) {  // chunk order, as k_range_final sums them
+        partial->st_sum_kept += p.st_sum_kept;
+        partial->st_n_kept += p.st_n_kept;
+        partial->max_m_power = std::max(partial->max_m_power, p.max_m_power);
+        partial->max_s_power = std::max(partial->max_s_power, p.max_s_power);
+    }
+    partial->n_shortterm = d.n_hops + d.st_pre >= 30 ? d.n_hops + d.st_pre - 29 : 0;
+    partial->range_ok = range_ok ? 1 : 0;
     ctx->shard_open = false;
     return HR_OK;
 }
@@ -989,31 +1029,46 @@ int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_r
     HIPCHK(hipSetDevice(ctx->cfg.device));
     if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
     hipStream_t st = ctx->stream;
-    std::vector<uint32_t> hist(kEbuBins);
+    std::vector<uint32_t> hist(2 * kEbuBins);  // gating histogram, then the short-term one
     for (int i = 0; i < kEbuBins; i++) {
-        if (red->hist[i] > 0xffffffffull) return HR_ERR_TOO_LARGE;
+        if (red->hist[i] > 0xffffffffull || red->st_hist[i] > 0xffffffffull) return HR_ERR_TOO_LARGE;
         hist[i] = static_cast<uint32_t>(red->hist[i]);
+        hist[kEbuBins + i] = static_cast<uint32_t>(red->st_hist[i]);
     }
+    // the reduced sums enter as the single "chunk" of a stand-in track
+    GatePart gp{};
+    gp.sum_kept = red->sum_kept;
+    gp.n_kept = red->n_kept;
+    gp.st_sum_kept = red->st_sum_kept;
+    gp.st_n_kept = red->st_n_kept;
+    gp.max_m_power = red->max_m_power;
+    gp.max_s_power = red->max_s_power;
+    TrackDesc d{};
+    d.n_blocks = red->n_blocks;
+    d.n_hops = red->n_shortterm ? red->n_shortterm + 29 : 0;
+    d.part_base = 0;
+    d.n_parts = 1;
     TrackOut o{};
-    o.sum_kept = red->sum_kept;
-    o.n_kept = red->n_kept;
-    o.n_blocks = red->n_blocks;
-    TrackDesc d{};  // k_gate_final only reads n_blocks/blk_base in HR_GATE_EXACT
     int rc = upload(ctx->hist, hist.data(), kEbuBins * sizeof(uint32_t), st);
+    if (!rc) rc = upload(ctx->st_hist, hist.data() + kEbuBins, kEbuBins * sizeof(uint32_t), st);
+    if (!rc) rc = upload(ctx->gate_parts, &gp, sizeof gp, st);
     if (!rc) rc = upload(ctx->outs, &o, sizeof o, st);
     if (!rc) rc = upload(ctx->tracks_d, &d, sizeof d, st);
     if (rc) return rc;
     if (!ctx->blk_powers.ensure(sizeof(double))) return HR_ERR_OOM;
     launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(),
                       ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(),
-                      ctx->ln_bounds.as<double>(), nullptr, false, ctx->outs.as<TrackOut>(), st);
+                      ctx->ln_bounds.as<double>(), ctx->gate_parts.as<GatePart>(), false, ctx->outs.as<TrackOut>(), st);
+    launch_range_stats(ctx->tracks_d.as<TrackDesc>(), 1, nullptr, 0, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(),
+                       ctx->blk_powers.as<double>(), ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(),
+                       ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), true, ctx->outs.as<TrackOut>(), st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     unsigned long long pk[kMaxCh] = {0};
     for (int c = 0; c < channels; c++) std::memcpy(&pk[c], &red->peak_per_ch[c], sizeof(double));
     std::memset(out, 0, sizeof *out);
-    fill_result(ctx, o, pk, channels, out, false);
+    fill_result(ctx, o, pk, channels, out, red->range_ok != 0);
     return HR_OK;
 }
 
@@ -1068,7 +1123,7 @@ int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *tr
     };
     int rc = on_all([&](int r) {
         return hr_shard_pass1(ctxs[r], &shard[r], r ? tail[r - 1].data() : nullptr, r + 1 < active ? head[r + 1].data() : nullptr,
-                              r == 0, r + 1 == active, &edge[r]);
+                              r == 0, r + 1 == active, cut[r] / hop, &edge[r]);
     });
     if (rc) return rc;
     rc = on_all([&](int r) { return hr_shard_pass2(ctxs[r], r ? &edge[r - 1] : nullptr, &part[r]); });
@@ -1080,6 +1135,13 @@ int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *tr
         red.n_kept += part[r].n_kept;
         red.n_blocks += part[r].n_blocks;
         for (int c = 0; c < HR_MAX_CH; c++) red.peak_per_ch[c] = std::max(red.peak_per_ch[c], part[r].peak_per_ch[c]);
+        for (int b = 0; b < kEbuBins; b++) red.st_hist[b] += part[r].st_hist[b];
+        red.st_sum_kept += part[r].st_sum_kept;
+        red.st_n_kept += part[r].st_n_kept;
+        red.n_shortterm += part[r].n_shortterm;
+        red.max_m_power = std::max(red.max_m_power, part[r].max_m_power);
+        red.max_s_power = std::max(red.max_s_power, part[r].max_s_power);
+        red.range_ok = r == 0 ? part[r].range_ok : std::min(red.range_ok, part[r].range_ok);
     }
     return hr_shard_finish(ctxs[0], &red, track->channels, out);
 }

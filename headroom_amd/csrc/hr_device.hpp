@@ -8,7 +8,8 @@
 namespace hr {
 
 constexpr int kPreRec = 6;   // hop records kept in front of hop 0 (left shard edge; zeros otherwise)
-constexpr int kPreHop = 3;   // hop sums kept in front of hop 0 (complete the 3 boundary blocks)
+constexpr int kPreHop = 29;  // hop-sum slots in front of hop 0: a shard's left neighbour fills them (3 s windows span 30 hops)
+constexpr int kPreBlk = 3;   // of those, the last 3 are recomputed from the neighbour's records and complete the 3 boundary blocks
 constexpr int kHalo = 16;    // frames of FIR halo on each side of a shard
 constexpr int kEbuBins = 8001;
 constexpr int kLnBins = 1000;
@@ -75,6 +76,10 @@ struct TrackDesc {
     uint8_t role;          // 0 ordinary track; 1 parent of stereo planes (measured through them: no work items of its
                            // own, only hop-sum slots and gating); 2 stereo plane of a parent
     uint32_t first_plane;  // role 1: index of the first of its (ch+1)/2 consecutive plane descriptors
+    int32_t st_pre;        // hop sums in front of hop 0 that are valid for the 3 s windows: 0, or kPreHop for a shard whose
+                           // left neighbour handed over its last 29
+    uint32_t pad3_;
+    uint64_t first_hop;    // index of hop 0 in the whole stream (libebur128 takes its range blocks on a 1 s grid)
     uint32_t part_base, n_parts;  // gating chunks of kGateChunk blocks (one workgroup each): slots of their partial sums
     float w[kMaxCh];
 };

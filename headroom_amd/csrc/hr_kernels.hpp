@@ -24,10 +24,11 @@ void launch_block_hist(const TrackDesc *tracks, const WorkItem *items, uint32_t 
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
                        const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st);
-// loudness range + maximum 400 ms / 3 s powers of whole tracks (after launch_block_hist: reads the block powers)
+// loudness range + maximum 400 ms / 3 s powers (after launch_block_hist: reads the block powers): the chunks' histograms
+// and partial sums, and with `finalize` the per-track result (n_items == 0: only that, from reduced partials)
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
                         const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
-                        uint32_t *st_hist, GatePart *parts, TrackOut *outs, hipStream_t st);
+                        uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st);
 // hop sums of the stereo planes of a split track -> the track's own (hop, channel) slots; one workgroup per parent
 void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
 // libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases/step) interleaved f64 frames

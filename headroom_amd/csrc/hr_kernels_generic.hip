@@ -159,7 +159,7 @@ __global__ void __launch_bounds__(64) k_hop_zero_state_list(const TrackDesc *__r
 }
 
 // ---------------------------------------------------------------------------------------------
-// carry hand-off + true hop energies.  One thread per (hop, channel), hops -kPreHop .. n_hops-1.
+// carry hand-off + true hop energies.  One thread per (hop, channel), hops -kPreBlk .. n_hops-1.
 // ---------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict__ tracks,
                                                      const RateDev *__restrict__ rates,
@@ -169,9 +169,9 @@ __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict
     const WorkItem it = items[blockIdx.x];
     const TrackDesc &t = tracks[it.track];
     const int C = t.ch;
-    // it.first counts (hop, channel) pairs from the first hop to combine: hop 0, or hop -kPreHop for a
+    // it.first counts (hop, channel) pairs from the first hop to combine: hop 0, or hop -kPreBlk for a
     // shard with a left neighbour (their sums complete the boundary blocks)
-    const int pre = t.blk_first < 0 ? kPreHop : 0;
+    const int pre = t.blk_first < 0 ? kPreBlk : 0;
     const uint64_t pair = it.first + threadIdx.x;
     const uint64_t total = (t.n_hops + pre) * C;
     if (pair >= total) return;
@@ -456,14 +456,16 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
     const int nbins = ln ? kLnBins : kEbuBins;
     for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
     __syncthreads();
-    const uint64_t n_s = t.n_hops >= 30 ? t.n_hops - 29 : 0;
+    // windows are counted by their LAST hop: a shard owns those that end in it, i.e. start at -st_pre or later
+    const uint64_t n_s = t.n_hops + t.st_pre >= 30 ? t.n_hops + t.st_pre - 29 : 0;
     const double bins = ln ? static_cast<double>(30 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
                            : static_cast<double>(static_cast<uint64_t>(t.fs) * 30 / 10);
     const double *H = hop_sums + t.hop_base + kPreHop * C;
     double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
     unsigned long long n_kept = 0;
     const uint64_t j_end = it.first + kGateChunk < n_s ? it.first + kGateChunk : n_s;
-    for (uint64_t j = it.first + threadIdx.x; j < j_end; j += blockDim.x) {
+    for (uint64_t jw = it.first + threadIdx.x; jw < j_end; jw += blockDim.x) {
+        const int64_t j = static_cast<int64_t>(jw) - t.st_pre;  // first hop of the window, relative to this shard
         double power = ln ? 0.0 : 1e-12;
         for (int c = 0; c < C; c++) {
             if (t.w[c] == 0.0f) continue;
@@ -482,7 +484,7 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
                 sum_kept += power;
                 n_kept++;
             }
-        } else if (j % 10 == 0 && power >= ln_bounds[0]) {
+        } else if ((static_cast<int64_t>(t.first_hop) + j) % 10 == 0 && power >= ln_bounds[0]) {
             int lo = 0, hi = kLnBins;
             do {
                 const int mid = (lo + hi) / 2;
@@ -613,7 +615,7 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
         o.st_rel_energy = rel_energy;
         o.max_m_power = max_m;
         o.max_s_power = max_s;
-        o.n_shortterm = t.n_hops >= 30 ? t.n_hops - 29 : 0;
+        o.n_shortterm = t.n_hops + t.st_pre >= 30 ? t.n_hops + t.st_pre - 29 : 0;
         o.lra_low_bin = any ? lo_bin : -1;
         o.lra_high_bin = any ? hi_bin : -1;
     }
@@ -621,13 +623,14 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
 
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
                         const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
-                        uint32_t *st_hist, GatePart *parts, TrackOut *outs, hipStream_t st)
+                        uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st)
 {
     if (!n_tracks) return;
     if (n_items)
         hipLaunchKernelGGL(k_range_stats, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, block_powers,
                            ln_bounds, st_hist, parts);
-    hipLaunchKernelGGL(k_range_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, st_hist, parts, ln_bounds, ln_energy,
+    if (finalize)
+        hipLaunchKernelGGL(k_range_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, st_hist, parts, ln_bounds, ln_energy,
                        outs);
 }
 

@@ -88,36 +88,48 @@ def exchange_edges(dist, edge, rank, active):
 
 
 def allreduce_partial(dist, partial):
-    """All-reduce of hr_shard_partial: counts and the kept-power sum add, the peaks take the maximum."""
+    """All-reduce of hr_shard_partial: histogram counts, block / window counts and the kept-power sums add, the peaks and
+    the maximum powers take the maximum, range_ok the minimum."""
     import torch
     dev = _comm_device(dist)
-    counts = np.empty(8001 + 2, dtype=np.int64)
+    counts = np.empty(2 * 8001 + 4, dtype=np.int64)
     counts[:8001] = np.ctypeslib.as_array(partial.hist).astype(np.int64)
-    counts[8001], counts[8002] = partial.n_kept, partial.n_blocks
+    counts[8001:16002] = np.ctypeslib.as_array(partial.st_hist).astype(np.int64)
+    counts[16002:] = partial.n_kept, partial.n_blocks, partial.st_n_kept, partial.n_shortterm
     tc = torch.from_numpy(counts).to(dev)
-    ts = torch.tensor([partial.sum_kept], dtype=torch.float64, device=dev)
-    tp = torch.from_numpy(np.ctypeslib.as_array(partial.peak_per_ch).copy()).to(dev)
+    ts = torch.tensor([partial.sum_kept, partial.st_sum_kept], dtype=torch.float64, device=dev)
+    mx = np.empty(MAX_CH + 3, dtype=np.float64)
+    mx[:MAX_CH] = np.ctypeslib.as_array(partial.peak_per_ch)
+    mx[MAX_CH:] = partial.max_m_power, partial.max_s_power, -float(partial.range_ok)  # max of the negative = minimum
+    tp = torch.from_numpy(mx).to(dev)
     dist.all_reduce(tc, op=dist.ReduceOp.SUM)
     dist.all_reduce(ts, op=dist.ReduceOp.SUM)
     dist.all_reduce(tp, op=dist.ReduceOp.MAX)
     out = HrShardPartial()
     c = tc.cpu().numpy()
     np.ctypeslib.as_array(out.hist)[:] = c[:8001].astype(np.uint64)
-    out.n_kept, out.n_blocks = int(c[8001]), int(c[8002])
-    out.sum_kept = float(ts.cpu()[0])
-    np.ctypeslib.as_array(out.peak_per_ch)[:] = tp.cpu().numpy()
+    np.ctypeslib.as_array(out.st_hist)[:] = c[8001:16002].astype(np.uint64)
+    out.n_kept, out.n_blocks, out.st_n_kept, out.n_shortterm = (int(v) for v in c[16002:])
+    sums = ts.cpu().numpy()
+    out.sum_kept, out.st_sum_kept = float(sums[0]), float(sums[1])
+    m = tp.cpu().numpy()
+    np.ctypeslib.as_array(out.peak_per_ch)[:] = m[:MAX_CH]
+    out.max_m_power, out.max_s_power = float(m[MAX_CH]), float(m[MAX_CH + 1])
+    out.range_ok = int(round(-m[MAX_CH + 2]))
     return out
 
 
-def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels):
+def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels, first_hop=0):
     """One rank's part of a time-sharded stream.  `shard_spec` is this rank's TrackSpec (None for a rank
-    with an empty shard).  Every rank of the group must call this; all get the same result dict."""
+    with an empty shard); first_hop = index of its first hop in the whole stream (cut // hop length).  Every rank of
+    the group must call this; all get the same result dict."""
     part = HrShardPartial()
+    part.range_ok = 1  # a rank that sits the passes out does not veto the range statistics
     if shard_spec is not None and rank < active:
         head = meter.shard_head(shard_spec)
         # pass 1 needs the neighbours' 16-frame halos: tails travel right, heads travel left
         left_tail, right_head = _exchange_halos(dist, meter, shard_spec, head, rank, active)
-        edge = meter.shard_pass1(shard_spec, left_tail, right_head)
+        edge = meter.shard_pass1(shard_spec, left_tail, right_head, first_hop)
         left_edge = exchange_edges(dist, edge, rank, active)
         part = meter.shard_pass2(left_edge)
     red = allreduce_partial(dist, part)

@@ -92,8 +92,8 @@ typedef struct hr_result {
     int32_t reserved;
     /* The other numbers FFmpeg prints for a file (loudnorm JSON `input_lra`, `input_thresh` = rel_threshold_lufs;
      * the ebur128 summary's "Loudness range" block), which src/analyzer.rs:102-106 leaves unread: SURVEY.md 8f.
-     * hr_analyze_batch fills them; the time-shard entry points (a 3 s window spans more than their 3-hop
-     * boundary exchange) set them to NaN. */
+     * hr_analyze_batch and the time-shard entry points fill them (NaN from the latter when a shard other than the last
+     * is shorter than 32 hops and cannot hand the energies of 29 hops to its neighbour). */
     double loudness_range_lu;  /* LRA; 0 when no short-term block passes the gates                     */
     double lra_low_lufs;       /* loudness at the 10 % point (NaN without a block)                     */
     double lra_high_lufs;      /* loudness at the 95 % point                                           */
@@ -140,6 +140,10 @@ typedef struct hr_shard_edge {
     double rec[6][HR_MAX_CH][9];
     double tail[16][HR_MAX_CH]; /* last 16 frames: FIR halo and filter input history */
     uint64_t n_hops;
+    /* energies of the shard's last 29 hops, oldest first: the right neighbour's first 3 s windows reach back that far */
+    double hop_tail[29][HR_MAX_CH];
+    int32_t range_ok;           /* hop_tail is complete (the shard has the 32 hops that takes; 29 for the first) */
+    int32_t reserved;
 } hr_shard_edge;
 
 typedef struct hr_shard_partial {
@@ -148,6 +152,14 @@ typedef struct hr_shard_partial {
     uint64_t n_kept;
     uint64_t n_blocks;
     double peak_per_ch[HR_MAX_CH];
+    /* loudness range and maxima: the 3 s windows that END in this shard (sum / max like the fields above) */
+    uint64_t st_hist[8001];
+    double st_sum_kept;
+    uint64_t st_n_kept;
+    uint64_t n_shortterm;
+    double max_m_power, max_s_power; /* reduce with max */
+    int32_t range_ok;                /* reduce with min: 0 when a shard was too short to hand its 29 hop energies on */
+    int32_t reserved;
 } hr_shard_partial;
 
 /* The first 16 frames of a shard as doubles, head[16][HR_MAX_CH]: what its left neighbour needs as
@@ -156,9 +168,10 @@ int hr_shard_head(hr_ctx *ctx, const hr_track *shard, double *head);
 /* Phase 1: K-weighting of every hop from zero state + true peak.  left_tail / right_head are the 16
  * frames before / after the shard ([16][HR_MAX_CH] doubles: the left neighbour's hr_shard_edge.tail
  * and the right neighbour's hr_shard_head; NULL at the stream's ends, is_first / is_last).  Writes
- * this shard's right edge. */
+ * this shard's right edge.  first_hop: index of the shard's first hop in the whole stream (first frame / hop length;
+ * only HR_GATE_LOUDNORM's loudness range reads it: libebur128 takes its range blocks on a 1 s grid). */
 int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head,
-                   int is_first, int is_last, hr_shard_edge *right_edge_out);
+                   int is_first, int is_last, uint64_t first_hop, hr_shard_edge *right_edge_out);
 /* Phase 2: IIR carry hand-off from the left neighbour's edge (NULL for the first shard), the three
  * boundary blocks, and this shard's gating partial. */
 int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left_edge, hr_shard_partial *partial_out);

@@ -40,8 +40,8 @@ class RecordingMeter:
     def shard_tail(self, spec):
         return self._frames(spec, slice(-16, None))
 
-    def shard_pass1(self, spec, left_tail, right_head):
-        self.seen["left_tail"], self.seen["right_head"] = left_tail, right_head
+    def shard_pass1(self, spec, left_tail, right_head, first_hop=0):
+        self.seen["left_tail"], self.seen["right_head"], self.seen["first_hop"] = left_tail, right_head, first_hop
         e = hr.HrShardEdge()
         e.n_hops = spec.pcm.shape[0] // 4800
         np.ctypeslib.as_array(e.rec)[:] = 1000.0 * self.rank + np.arange(6 * 8 * 9).reshape(6, 8, 9)
@@ -58,6 +58,13 @@ class RecordingMeter:
         p.n_blocks = 100 + self.rank
         p.peak_per_ch[0] = 0.25 * (self.rank + 1)
         p.peak_per_ch[1] = 1.0 / (self.rank + 1)
+        p.st_hist[100 + self.rank] = 3
+        p.st_sum_kept = 0.25 * (self.rank + 1)
+        p.st_n_kept = 2 + self.rank
+        p.n_shortterm = 50 + self.rank
+        p.max_m_power = 1.0 + self.rank
+        p.max_s_power = 5.0 - self.rank
+        p.range_ok = 0 if self.rank == 1 else 1
         return p
 
     def shard_finish(self, red, channels):
@@ -102,7 +109,8 @@ def mode_cpu(rank, world):
     pcm = rng.standard_normal((frames, 2))
     m = RecordingMeter(rank)
     spec = FakeSpec(pcm[cuts[rank]:cuts[rank + 1]])
-    red = sharded.analyze_stream_shard(dist, m, spec, rank, world, 2)
+    red = sharded.analyze_stream_shard(dist, m, spec, rank, world, 2, first_hop=cuts[rank] // 4800)
+    assert m.seen["first_hop"] == cuts[rank] // 4800
     if rank > 0:
         assert np.array_equal(m.seen["left_tail"][:, :2], pcm[cuts[rank] - 16:cuts[rank]])
         le = m.seen["left_edge"]
@@ -122,6 +130,10 @@ def mode_cpu(rank, world):
     assert red.sum_kept == sum(0.5 + r for r in range(world))
     assert red.n_kept == sum(10 + r for r in range(world)) and red.n_blocks == sum(100 + r for r in range(world))
     assert red.peak_per_ch[0] == 0.25 * world and red.peak_per_ch[1] == 1.0 and red.peak_per_ch[2] == 0.0
+    assert all(red.st_hist[100 + r] == 3 for r in range(world)) and red.st_hist[100 + world] == 0
+    assert red.st_sum_kept == sum(0.25 * (r + 1) for r in range(world)) and red.st_n_kept == sum(2 + r for r in range(world))
+    assert red.n_shortterm == sum(50 + r for r in range(world))
+    assert red.max_m_power == float(world) and red.max_s_power == 5.0 and red.range_ok == 0   # rank 1 vetoed
 
     # --- a rank with an empty shard sits the passes out but joins the reduction --------------------
     m2 = RecordingMeter(rank)
@@ -143,7 +155,7 @@ def mode_gpu(rank, world):
         # one long stream, cut in time
         cuts = sharded.cut_stream(pcm.shape[0], fs, world)
         spec = hr.TrackSpec(pcm[cuts[rank]:cuts[rank + 1]].copy(), fs)
-        got = sharded.analyze_stream_shard(dist, m, spec, rank, world, 2)
+        got = sharded.analyze_stream_shard(dist, m, spec, rank, world, 2, first_hop=cuts[rank] // 4800)
         whole = m.analyze(pcm, fs)
         ref = oracle.measure(pcm, fs)
         assert got["n_blocks"] == whole["n_blocks"] == ref["n_blocks"], (got, whole)
@@ -151,9 +163,11 @@ def mode_gpu(rank, world):
         assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
         assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
         assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+        for k in ("loudness_range_lu", "lra_low_lufs", "lra_high_lufs", "max_momentary_lufs", "max_shortterm_lufs"):
+            assert abs(got[k] - whole[k]) < 1e-9, (k, got, whole)   # 83 hops over the ranks: every shard has its 32
         # the same with the shard resident in HBM (device pointers, offset view for the tail)
         dev = torch.from_numpy(pcm[cuts[rank]:cuts[rank + 1]].copy()).cuda()
-        got_d = sharded.analyze_stream_shard(dist, m, hr.TrackSpec(dev, fs), rank, world, 2)
+        got_d = sharded.analyze_stream_shard(dist, m, hr.TrackSpec(dev, fs), rank, world, 2, first_hop=cuts[rank] // 4800)
         # (the time-shard path reports the range statistics as NaN, and NaN != NaN)
         assert all(got_d[k] == got[k] or (got_d[k] != got_d[k] and got[k] != got[k]) for k in got), (got_d, got)
         # a batch of independent tracks, split over the ranks

@@ -211,6 +211,14 @@ def test_synth_fill_matches_oracle_generator(oracle, meters):
         assert np.array_equal(buf.cpu().numpy(), ref)
 
 
+RANGE_KEYS = ("loudness_range_lu", "lra_low_lufs", "lra_high_lufs", "lra_threshold_lufs", "max_momentary_lufs",
+              "max_shortterm_lufs")
+
+
+def same_range(a, b, tol=1e-9):
+    return all((math.isnan(a[k]) and math.isnan(b[k])) or a[k] == b[k] or abs(a[k] - b[k]) < tol for k in RANGE_KEYS)
+
+
 def test_time_shards_equal_whole_stream(oracle, meters):
     """BASELINE config 5 on one device: 3 shards with IIR carry hand-off, boundary blocks, FIR halos."""
     fs = 48000
@@ -229,7 +237,7 @@ def test_time_shards_equal_whole_stream(oracle, meters):
         for i, s in enumerate(shards):
             left_tail = np.ascontiguousarray(np.ctypeslib.as_array(edges[i - 1].tail)) if i else None
             right_head = heads[i + 1] if i < 2 else None
-            edges.append(m2[i].shard_pass1(s, left_tail, right_head))
+            edges.append(m2[i].shard_pass1(s, left_tail, right_head, first_hop=cuts[i] // 4800))
         for i in range(3):
             partials.append(m2[i].shard_pass2(edges[i - 1] if i else None))
         red = hr.HrShardPartial()
@@ -241,6 +249,14 @@ def test_time_shards_equal_whole_stream(oracle, meters):
             red.n_blocks += p.n_blocks
             for c in range(2):
                 red.peak_per_ch[c] = max(red.peak_per_ch[c], p.peak_per_ch[c])
+            for b in range(8001):
+                red.st_hist[b] += p.st_hist[b]
+            red.st_sum_kept += p.st_sum_kept
+            red.st_n_kept += p.st_n_kept
+            red.n_shortterm += p.n_shortterm
+            red.max_m_power = max(red.max_m_power, p.max_m_power)
+            red.max_s_power = max(red.max_s_power, p.max_s_power)
+        red.range_ok = min(p.range_ok for p in partials)
         got = m2[0].shard_finish(red, 2)
         for mm in m2:
             mm.close()
@@ -249,6 +265,8 @@ def test_time_shards_equal_whole_stream(oracle, meters):
         assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
         assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
         assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+        # the middle shard has 7 hops: too short to hand 29 hop energies on, so the range statistics are withheld
+        assert [e.range_ok for e in edges] == [0, 0, 1] and all(math.isnan(got[k]) for k in RANGE_KEYS)
 
 
 def test_full_size_track_properties(oracle, meters):
@@ -363,6 +381,9 @@ def test_analyze_stream_sharded_in_process(oracle, meters, gate):
             assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
             assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
             assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+            # 31 + 32 + 32 hops: every shard can hand its last 29 hop energies on, the 3 s windows match the whole stream's
+            assert same_range(got, whole), (got, whole)
+            assert got["loudness_range_lu"] > 0.0 and math.isfinite(got["max_shortterm_lufs"])
         short = pcm[: 4800 * 8 + 100].copy()  # eight hops: one shard only
         got = hr.analyze_stream_sharded(ms, hr.TrackSpec(short, fs))
         ref = oracle.measure(short, fs, gate_mode=GATES[gate])
