@@ -74,6 +74,7 @@ struct hr_ctx {
     std::vector<uint32_t> rate_fs;
     std::vector<RateDev> rates_h;
     std::vector<void *> rate_allocs;
+    std::vector<std::pair<uint32_t, const double *>> swr_banks;  // libswresample banks for hr_loudnorm_first_pass, per rate
     DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, unit_tap;
 
     // workspace (grow-only)
@@ -1213,11 +1214,21 @@ int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_res
                     // (a grown staging buffer is a new allocation: hipFree of the old one waits for the work that reads it)
                     src = ctx->stage.p;
                 }
-                const int ri = rate_index(ctx, t.sample_rate);
-                if (ri < 0) { rc = ri; break; }
-                const RateDev &rd = ctx->rates_h[ri];
-                if (rd.swr_phases > 0)
-                    launch_resample_swr(t.fmt, src, t.frames, t.channels, rd.swr_phases, rd.swr_step, rd.swr_taps, dst, st);
+                // always libswresample's bank, whatever interpolator the context's own tables hold
+                const RateTables *rt = rate_tables(t.sample_rate);
+                const double *bank = nullptr;
+                for (const auto &e : ctx->swr_banks)
+                    if (e.first == t.sample_rate) bank = e.second;
+                if (!bank && rt->swr_phases > 0) {
+                    void *p = nullptr;
+                    if (hipMalloc(&p, rt->swr_taps.size() * sizeof(double)) != hipSuccess) { (void)hipGetLastError(); rc = HR_ERR_OOM; break; }
+                    ctx->rate_allocs.push_back(p);
+                    if (hipMemcpy(p, rt->swr_taps.data(), rt->swr_taps.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = HR_ERR_HIP; break; }
+                    bank = static_cast<const double *>(p);
+                    ctx->swr_banks.emplace_back(t.sample_rate, bank);
+                }
+                if (rt->swr_phases > 0)
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, rt->swr_phases, rt->swr_step, bank, dst, st);
                 else  // 192 kHz input: the resampler passes it through; the f64 copy keeps one code path
                     launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, ctx->unit_tap.as<double>(), dst, st);
             }

@@ -1245,10 +1245,9 @@ static void launch_split_geom(uint32_t n_items, hipStream_t st, const TrackDesc 
                               unsigned long long *peaks, int wave_map)
 {
     constexpr int lds = split_lds(PAIRS, RING);
-    // more than 64 KiB of dynamic LDS has to be asked for once per kernel
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_split<MT, SMALL, PAIRS, RING>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)attr;
+    // more than 64 KiB of dynamic LDS has to be asked for (per device: contexts of one process may sit on several GPUs)
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_split<MT, SMALL, PAIRS, RING>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     k_fused_split<MT, SMALL, PAIRS, RING><<<dim3(n_items / PAIRS), dim3(PAIRS * 128), lds, st>>>(
         tracks, rates, items, recs, cands, fs.cand_cnt, fs.tpb, fs.overflow, peaks, wave_map);
 }

@@ -511,6 +511,12 @@ def test_loudnorm_first_pass_matches_oracle(oracle, meters):
     check_against_oracle(oracle, m, pcm, fs)
     bad = m.loudnorm_first_pass([hr.TrackSpec(signals.seeded_noise(1, 1000, 2), 384000)])
     assert bad[0]["status"] == hr.ERR_RATE
+    # a context whose own tables hold the BS.1770 bank still resamples with libswresample's
+    mb = meters("ebur128", "bs1770")
+    mb.analyze(pcm, fs)                                   # builds the context's tables for this rate first
+    g = mb.loudnorm_first_pass([hr.TrackSpec(pcm, fs)])[0]
+    ref = oracle.loudnorm_measure(pcm, fs)
+    assert g["peak_per_ch"] == ref["peak_per_ch"] and abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
 
 
 def test_concurrent_callers_share_one_context(oracle, meters):
