@@ -151,7 +151,7 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     rd.swr_phases = phases;
     rd.swr_step = bs ? rt->bs_step : rt->swr_step;
     rd.swr_l1 = bs ? rt->bs_l1 : rt->swr_l1;
-    rd.tp_passthru0 = bs ? 0 : 1;
+    rd.tp_passthru0 = (!bs && rt->swr_step == 1) ? 1 : 0;  // every input frame is a phase-0 output (integer ratio)
     if (phases > 0) {
         void *tp = nullptr;
         HIPCHK(hipMalloc(&tp, taps.size() * sizeof(double)));

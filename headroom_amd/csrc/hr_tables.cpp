@@ -292,7 +292,9 @@ const RateTables *rate_tables(uint32_t fs)
     rt->k = kweight_coeffs(static_cast<double>(fs));
     build_carry(*rt);
     build_swr(*rt);
-    build_tp_tiles(rt->swr_phases, rt->swr_step, rt->swr_taps, true, rt->tp_atab, rt->tp_np, rt->tp_mt, rt->tp_max_out);
+    // (the sample peak stands in for phase 0 only where EVERY input frame is a phase-0 output, i.e. at integer ratios:
+    // at 44.1 kHz only every 147th frame is one, and an isolated peak between two of them is not an output at all)
+    build_tp_tiles(rt->swr_phases, rt->swr_step, rt->swr_taps, rt->swr_step == 1, rt->tp_atab, rt->tp_np, rt->tp_mt, rt->tp_max_out);
     build_bs1770(*rt);
     build_tp_tiles(rt->bs_phases, rt->bs_step, rt->bs_taps, false, rt->bs_atab, rt->bs_np, rt->bs_mt, rt->bs_max_out);
     const RateTables *p = rt.get();

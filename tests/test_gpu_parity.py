@@ -559,3 +559,23 @@ def test_bs1770_mode_accepts_rates_libswresample_mode_rejects(oracle, meters):
     pcm = signals.seeded_noise(77, 22050 * 3, 2, -9.0)
     check_against_oracle(oracle, meters("ebur128", "bs1770"), pcm, 22050, "ebur128", "bs1770")
     assert meters().analyze(pcm, 22050)["status"] == hr.ERR_RATE      # 1280 phases: swr would interpolate between phases
+
+
+@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("fs", [44100, 88200, 48000])
+def test_isolated_peaks_between_output_positions(oracle, meters, fs, engine):
+    """At 44.1 kHz only every 147th input frame is itself a 192 kHz output (at 88.2 kHz likewise, at 48 kHz every frame
+    is): the largest sample of a sparse signal is then no output at all and the true peak is BELOW the sample peak.
+    (Found by tools/soak_long.py: the fused kernel took the sample peak for an output at every rate.)"""
+    n = fs * 3 + 77
+    pcm = np.zeros((n, 2), np.float32)
+    rng = np.random.default_rng(fs)
+    idx = rng.integers(200, n - 200, size=40)
+    idx = idx[idx % 147 != 0]
+    pcm[idx, 0] = rng.uniform(0.2, 0.95, size=idx.size).astype(np.float32)
+    pcm[idx[::2] + 50, 1] = -0.9
+    got, ref = check_against_oracle(oracle, meters(engine=engine), pcm, fs)
+    if fs != 48000:
+        assert got["peak_per_ch"][0] < float(np.abs(pcm[:, 0]).max())
+    else:
+        assert got["peak_per_ch"][0] >= float(np.abs(pcm[:, 0]).max())
