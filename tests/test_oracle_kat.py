@@ -101,6 +101,28 @@ def test_true_peak_44k1_uses_640_phase_bank(oracle):
     assert abs(20 * np.log10(tp[0]) - (-6.02)) < 0.05
 
 
+def test_isolated_impulse_true_peak_follows_the_output_grid(oracle):
+    """44.1 -> 192 kHz: output m sits at input time m*147/640, so only every 147th input frame is itself an output.  The
+    true peak of an isolated impulse is the largest bank tap that any output puts on it: the amplitude on the grid,
+    less between grid points (down to sinc(0.115) ~ 0.978 half way between two outputs)."""
+    P, step, taps = oracle.swr_bank(44100)
+    for pos in (147 * 20, 147 * 20 + 1, 147 * 20 + 73, 147 * 21 - 1, 3001):
+        x = np.zeros((8000, 2), np.float32)
+        x[pos, 0] = 0.75
+        best = 0.0
+        for m in range((pos - 20) * P // step, (pos + 20) * P // step):
+            u, ph = divmod(m * step, P)
+            k = pos - u + 15
+            if 0 <= k < 32:
+                best = max(best, abs(float(np.float32(0.75)) * taps[ph][k]))
+        tp = oracle.true_peak(x, 44100, oracle.TP_SWR192K)
+        assert tp[0] == best and tp[1] == 0.0
+        if pos % 147 == 0:
+            assert tp[0] == 0.75
+        else:
+            assert 0.97 * 0.75 < tp[0] < 0.75
+
+
 def test_swr_bank_interpolates_a_bandlimited_sine(oracle):
     # the 48k bank applied to a 5 kHz sine reproduces the sine on the 192 kHz grid
     P, step, taps = oracle.swr_bank(48000)
