@@ -75,6 +75,7 @@ int probe_wav(const uint8_t *b, size_t n, uint64_t total, hr_pcm_info *o)
             int tag = le16(b + body);
             o->channels = le16(b + body + 2);
             o->sample_rate = le32(b + body + 4);
+            if (o->sample_rate == 0) return HR_ERR_RATE;
             const int bits = le16(b + body + 14);
             o->channel_mask = 0;
             if (tag == 0xFFFE) {

@@ -53,6 +53,9 @@ def test_wav_rejects_what_is_not_pcm():
     bad = bytearray(data)
     bad[34:36] = (8).to_bytes(2, "little")  # 8-bit PCM
     assert hr.pcm_probe(bytes(bad))[0] == hr.ERR_FORMAT
+    bad = bytearray(data)
+    bad[24:28] = (0).to_bytes(4, "little")  # sample rate 0 (found by tools/fuzz_probe.py)
+    assert hr.pcm_probe(bytes(bad))[0] == hr.ERR_RATE
     assert hr.pcm_probe(b"RIFF\x00\x00\x00\x00WAVE")[0] == hr.ERR_FORMAT
     assert hr.pcm_probe(b"OggS" + b"\0" * 40)[0] == hr.ERR_FORMAT
     assert hr.pcm_probe(b"")[0] == hr.ERR_FORMAT
