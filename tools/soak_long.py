@@ -57,24 +57,36 @@ def main():
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         cases = [make(rng, k) for k in KINDS]
-        for tp in (0, 1):
-            m = hr.Meter(device=0, gate_mode=0, tp_mode=tp)
+        gate = seed % 3
+        for tp in (0, 1, 2):
+            m = hr.Meter(device=0, gate_mode=gate, tp_mode=tp)
             try:
                 got = m.analyze_batch([hr.TrackSpec(p, fs) for p, fs, _ in cases])
+                first = m.loudnorm_first_pass([hr.TrackSpec(p[: fs * 6], fs) for p, fs, _ in cases]) if tp == 0 else None
             finally:
                 m.close()
             for (pcm, fs, tag), g in zip(cases, got):
-                ref = oracle_lib.measure(pcm, fs, gate_mode=0, tp_mode=tp)
-                ok = g["status"] == 0 and g["n_blocks"] == ref["n_blocks"] and g["n_gated"] == ref["n_gated"]
-                if math.isfinite(ref["integrated_lufs"]):
-                    ok = ok and abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
-                else:
-                    ok = ok and g["integrated_lufs"] == ref["integrated_lufs"]
-                ok = ok and g["peak_per_ch"] == ref["peak_per_ch"]
-                if not ok:
-                    print("MISMATCH seed", seed, "tp", tp, tag, g, ref, flush=True)
-                    sys.exit(1)
-            print(f"seed {seed} tp_mode {tp}: {len(cases)} tracks ok, {time.time() - t0:.0f} s", flush=True)
+                ref = oracle_lib.measure(pcm, fs, gate_mode=gate, tp_mode=tp)
+                check(g, ref, (seed, gate, tp, tag))
+            if first:
+                for (pcm, fs, tag), g in zip(cases, first):
+                    ref = oracle_lib.loudnorm_measure(pcm[: fs * 6], fs)
+                    check(g, ref, (seed, "loudnorm first pass", tag))
+            print(f"seed {seed} gate_mode {gate} tp_mode {tp}: {len(cases)} tracks ok, {time.time() - t0:.0f} s", flush=True)
+
+
+def check(g, ref, tag):
+    ok = g["status"] == 0 and g["n_blocks"] == ref["n_blocks"]
+    if "n_gated" in ref:
+        ok = ok and g["n_gated"] == ref["n_gated"]
+    if math.isfinite(ref["integrated_lufs"]):
+        ok = ok and abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+    else:
+        ok = ok and g["integrated_lufs"] == ref["integrated_lufs"]
+    ok = ok and g["peak_per_ch"] == ref["peak_per_ch"]
+    if not ok:
+        print("MISMATCH", tag, g, ref, flush=True)
+        sys.exit(1)
 
 
 if __name__ == "__main__":
