@@ -146,14 +146,102 @@ __global__ void __launch_bounds__(256) k_split_planes(const uint8_t *__restrict_
     }
 }
 
+// The same for whole blocks of 1024 frames with the channel count known at compile time: 16 bytes per lane in, four
+// frames per lane through LDS (the lane's chunk is CH*B dwords; an even chunk length is padded by one dword so that the
+// lanes spread over the banks), every sample cut out of its dword(s) by compile-time shifts, 32 bytes per lane and plane
+// out.  Needs a 16-byte aligned source; launch_split_planes sends the ragged end and anything else to the kernel above.
+template <int FMT, int CH>
+__global__ void __launch_bounds__(256) k_split_planes_wide(const uint8_t *__restrict__ src, float *__restrict__ dst, uint64_t n_blocks,
+                                                           uint64_t plane_floats)
+{
+    constexpr int B = FMT == 0 ? 4 : FMT == 1 ? 2 : 3;
+    constexpr int ND = CH * B;                       // dwords of four frames
+    constexpr int STRIDE = (ND & 1) ? ND : ND + 1;   // odd: conflict-free reads
+    constexpr int PLANES = (CH + 1) / 2;
+    __shared__ uint32_t lds[256 * STRIDE];
+    typedef unsigned uint4v __attribute__((ext_vector_type(4)));
+    for (uint64_t blk = blockIdx.x; blk < n_blocks; blk += gridDim.x) {
+        const uint4v *in = reinterpret_cast<const uint4v *>(src + blk * (1024ull * CH * B));
+#pragma unroll
+        for (int j = 0; j < (ND + 3) / 4; j++) {
+            const uint32_t q = threadIdx.x + 256u * j;  // 16-byte piece of the block
+            if (ND % 4 == 0 || q < 64u * ND) {
+                const uint4v u = in[q];
+#pragma unroll
+                for (int e = 0; e < 4; e++) {
+                    const uint32_t d = q * 4 + e;
+                    lds[d + (STRIDE != ND ? d / ND : 0)] = u[e];
+                }
+            }
+        }
+        __syncthreads();
+        uint32_t w[ND + 1];
+#pragma unroll
+        for (int d = 0; d < ND; d++) w[d] = lds[threadIdx.x * STRIDE + d];
+        w[ND] = 0;
+        __syncthreads();
+        const uint64_t f = blk * 1024 + threadIdx.x * 4;
+#pragma unroll
+        for (int p = 0; p < PLANES; p++) {
+            float v[4][2];
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+#pragma unroll
+                for (int j = 0; j < 2; j++) {
+                    const int c = 2 * p + j;
+                    if (c >= CH) { v[i][j] = 0.0f; continue; }
+                    const int byte = (i * CH + c) * B, d = byte >> 2, sh = (byte & 3) * 8;
+                    if constexpr (FMT == 0) {
+                        v[i][j] = __uint_as_float(w[d]);
+                    } else if constexpr (FMT == 1) {
+                        v[i][j] = static_cast<float>(static_cast<int32_t>(w[d] << (16 - sh)) >> 16) * (1.0f / 32768.0f);
+                    } else {
+                        const uint32_t bits = sh <= 8 ? w[d] >> sh : __funnelshift_r(w[d], w[d + 1], sh);
+                        v[i][j] = static_cast<float>(static_cast<int32_t>(bits << 8) >> 8) * (1.0f / 8388608.0f);
+                    }
+                }
+            float4 *o = reinterpret_cast<float4 *>(dst + p * plane_floats + f * 2);
+            o[0] = make_float4(v[0][0], v[0][1], v[1][0], v[1][1]);
+            o[1] = make_float4(v[2][0], v[2][1], v[3][0], v[3][1]);
+        }
+    }
+}
+
+template <int FMT>
+static bool launch_split_wide(const uint8_t *s, float *dst, uint64_t n_blocks, uint32_t channels, uint64_t plane_floats, hipStream_t st)
+{
+    const dim3 grid(static_cast<uint32_t>(n_blocks < 256 * 16 ? n_blocks : 256 * 16)), block(256);
+    switch (channels) {
+#define HR_SPLIT_CASE(C) case C: k_split_planes_wide<FMT, C><<<grid, block, 0, st>>>(s, dst, n_blocks, plane_floats); return true
+    HR_SPLIT_CASE(1); HR_SPLIT_CASE(2); HR_SPLIT_CASE(3); HR_SPLIT_CASE(4); HR_SPLIT_CASE(5); HR_SPLIT_CASE(6); HR_SPLIT_CASE(7); HR_SPLIT_CASE(8);
+#undef HR_SPLIT_CASE
+    default: return false;
+    }
+}
+
 void launch_split_planes(int fmt, const void *src, float *dst, uint64_t frames, uint32_t channels, uint64_t plane_floats,
                          hipStream_t st)
 {
     if (!frames) return;
+    const uint8_t *s = static_cast<const uint8_t *>(src);
+    // whole blocks of 1024 frames on the wide kernel (16-byte aligned source and planes), the rest on the generic one
+    uint64_t done = 0;
+    if ((reinterpret_cast<uintptr_t>(src) & 15) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (plane_floats & 3) == 0 &&
+        frames >= 1024) {
+        const uint64_t nb = frames / 1024;
+        const bool ok = fmt == 0 ? launch_split_wide<0>(s, dst, nb, channels, plane_floats, st)
+                      : fmt == 1 ? launch_split_wide<1>(s, dst, nb, channels, plane_floats, st)
+                                 : launch_split_wide<2>(s, dst, nb, channels, plane_floats, st);
+        if (ok) done = nb * 1024;
+    }
+    if (done == frames) return;
+    const uint32_t B = fmt == 0 ? 4 : fmt == 1 ? 2 : 3;
+    s += done * channels * B;
+    dst += done * 2;
+    frames -= done;
     uint64_t blocks = (frames + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     const dim3 grid(static_cast<uint32_t>(blocks)), block(256);
-    const uint8_t *s = static_cast<const uint8_t *>(src);
     if (fmt == 0) k_split_planes<0><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
     else if (fmt == 1) k_split_planes<1><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
     else k_split_planes<2><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
