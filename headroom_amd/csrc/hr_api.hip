@@ -85,6 +85,7 @@ struct hr_ctx {
     std::vector<FusedItem> h_fitems;
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<WorkItem> h_ovf_items, h_gate_items;
+    bool no_s16_direct = false;  // HR_NO_S16_DIRECT=1: stereo s16 is widened into f32 planes first, as before
     bool serial_tail = false;  // HR_SERIAL_TAIL=1 (timing experiments): tail kernels before the fused kernel, not beside it
     bool split = false;  // HR_FUSED_SPLIT=1: k_fused_split (K-weighting and true peak in separate waves) instead of k_fused_f32s
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
@@ -254,11 +255,14 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0), fsp(nt, 0);  // fused K-weighting / + true-peak screen / + sample peak
     for (size_t i = 0; i < nt; i++) {
         const TrackDesc &d = g.descs[i];
-        const bool ok = d.role != 1 && ctx->cfg.engine != 1 && d.fmt == HR_FMT_F32 && d.ch == 2 && d.n_hops >= 2 && d.hop >= 64 &&
-                        (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
+        bool ok = d.role != 1 && ctx->cfg.engine != 1 && (d.fmt == HR_FMT_F32 || d.fmt == HR_FMT_S16) && d.ch == 2 && d.n_hops >= 2 &&
+                  d.hop >= 64 && (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
+        const bool tp_ok = do_peaks && (ctx->cfg.tp_mode == HR_TP_SWR192K || ctx->cfg.tp_mode == HR_TP_BS1770) &&
+                           ctx->rates_h[d.rate_idx].tp_atab != nullptr;
+        // stereo s16 is read as it is by the full pass only (K-weighting + true-peak screen); see fused_s16()
+        if (d.fmt == HR_FMT_S16 && !tp_ok) ok = false;
         fkw[i] = ok;
-        ftp[i] = ok && do_peaks && (ctx->cfg.tp_mode == HR_TP_SWR192K || ctx->cfg.tp_mode == HR_TP_BS1770) &&
-                 ctx->rates_h[d.rate_idx].tp_atab != nullptr;
+        ftp[i] = ok && tp_ok;
         // the peak is the plain sample peak: HR_TP_SAMPLE, 192 kHz input (nothing to interpolate)
         const bool plain = ctx->cfg.tp_mode == HR_TP_SAMPLE || ctx->rates_h[d.rate_idx].swr_phases == 0;
         fsp[i] = ok && do_peaks && !ftp[i] && plain;
@@ -266,8 +270,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
-    // class 6 = K-weight only, class 7 = K-weight + sample peak
-    constexpr int kFusedClasses = 8;
+    // class 6 = K-weight only, class 7 = K-weight + sample peak, classes 8..13 = classes 0..5 reading stereo s16
+    constexpr int kFusedClasses = 14;
     size_t class_off[kFusedClasses + 1];
     // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
     // mixes rates: every (class, rate) run is padded to a multiple of 4 with n_rows == 0 copies of its last item.
@@ -278,7 +282,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             for (size_t i = 0; i < nt; i++) {
                 if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri)) continue;
                 const RateDev &rd = ctx->rates_h[ri];
-                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) : fsp[i] ? 7 : 6;
+                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : 0) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
                 const uint64_t interior = g.descs[i].n_hops - 1;
                 for (uint64_t h = 0; h < interior; h += 64)
@@ -314,12 +318,14 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         hop_span[f].n = items.size() - hop_span[f].off;
     }
     // last hop of the fused tracks (all f32): one lane per (track, channel)
-    Span tail_span;
-    tail_span.off = items.size();
-    for (size_t i = 0; i < nt; i++)
-        if (fkw[i])
-            for (uint32_t c = 0; c < g.descs[i].ch; c++) items.push_back({static_cast<uint32_t>(i), c, g.descs[i].n_hops - 1});
-    tail_span.n = items.size() - tail_span.off;
+    Span tail_span[2];  // f32, s16
+    for (int f = 0; f < 2; f++) {
+        tail_span[f].off = items.size();
+        for (size_t i = 0; i < nt; i++)
+            if (fkw[i] && g.fmts[i] == f)
+                for (uint32_t c = 0; c < g.descs[i].ch; c++) items.push_back({static_cast<uint32_t>(i), c, g.descs[i].n_hops - 1});
+        tail_span[f].n = items.size() - tail_span[f].off;
+    }
     comb_span.off = items.size();
     for (size_t i = 0; i < nt; i++) {
         const auto &d = g.descs[i];
@@ -376,7 +382,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
     for (int f = 0; f < 5; f++)
         launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), tail_st);
-    launch_hop_zero_state_list(HR_FMT_F32, dt, dr, di + tail_span.off, static_cast<uint32_t>(tail_span.n), ctx->recs.as<HopRec>(), tail_st);
+    for (int f = 0; f < 2; f++)
+        launch_hop_zero_state_list(f, dt, dr, di + tail_span[f].off, static_cast<uint32_t>(tail_span[f].n), ctx->recs.as<HopRec>(), tail_st);
     if (do_peaks) {
         for (int f = 0; f < 5; f++)
             for (int kind = 0; kind < 2; kind++) {
@@ -402,8 +409,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             const bool tp = cls < 6;
             launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
                               ctx->peaks.as<unsigned long long>(),
-                              tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1), cls,
-                              cls == 7 ? (dbg | 64) : dbg, st);
+                              cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
+                              cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -526,10 +533,14 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     HIPCHK(hipStreamSynchronize(st));
     std::vector<WorkItem> &items = ctx->h_ovf_items;
     items.clear();
-    for (size_t i = 0; i < nt; i++) {
-        if (!ctx->h_ftp[i] || !ovf[i]) continue;
-        const uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
-        for (uint64_t n = 0; n < end; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
+    size_t fmt_end[2];  // f32 items first, then s16
+    for (int f = 0; f < 2; f++) {
+        for (size_t i = 0; i < nt; i++) {
+            if (!ctx->h_ftp[i] || !ovf[i] || g.fmts[i] != f) continue;
+            const uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
+            for (uint64_t n = 0; n < end; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
+        }
+        fmt_end[f] = items.size();
     }
     if (std::getenv("HR_DEBUG")) {
         std::vector<unsigned> cnt(ctx->h_fitems.size());
@@ -548,9 +559,12 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     // the last item of a track may reach a little past `end`: those positions are redone too, harmlessly
     int rc = upload(ctx->ovf_items, items.data(), items.size() * sizeof(WorkItem), st);
     if (rc) return rc;
-    launch_true_peak_generic(HR_FMT_F32, HR_TP_SWR192K, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(),
-                             ctx->ovf_items.as<WorkItem>(), static_cast<uint32_t>(items.size()),
-                             kPeakSpan, ctx->peaks.as<unsigned long long>(), st);
+    for (int f = 0; f < 2; f++) {
+        const size_t b = f ? fmt_end[0] : 0;
+        launch_true_peak_generic(f, HR_TP_SWR192K, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(),
+                                 ctx->ovf_items.as<WorkItem>() + b, static_cast<uint32_t>(fmt_end[f] - b),
+                                 kPeakSpan, ctx->peaks.as<unsigned long long>(), st);
+    }
     HIPCHK(hipGetLastError());
     return HR_OK;
 }
@@ -558,6 +572,18 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
 // Every f32 / s16 / s24 track that is not already stereo f32 is split on the device into stereo f32 planes (exactly)
 // so that it takes the fused kernel: mono, 5.1, 7.1, integer stereo.  The generic kernels, one thread per hop, are two
 // orders of magnitude slower.  s32 / f64 samples do not fit f32 and stay generic.
+// Stereo s16 is read directly by the fused kernel's full pass (K-weighting + true-peak screen): needs a true-peak mode
+// with a tile table at this rate and a 16-byte aligned buffer.  (Other cases are widened into f32 planes first.)
+bool fused_s16(const hr_ctx *ctx, const hr_track &t, const void *dev)
+{
+    if (t.fmt != HR_FMT_S16 || t.channels != 2 || ctx->no_s16_direct) return false;
+    if (ctx->cfg.tp_mode != HR_TP_SWR192K && ctx->cfg.tp_mode != HR_TP_BS1770) return false;
+    const RateTables *rt = rate_tables(t.sample_rate);
+    if (!rt) return false;
+    const bool has_tiles = ctx->cfg.tp_mode == HR_TP_BS1770 ? !rt->bs_atab.empty() : !rt->tp_atab.empty();
+    return has_tiles && (reinterpret_cast<uintptr_t>(dev) & 15) == 0;
+}
+
 bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = nullptr)
 {
     const uint32_t hop = t.sample_rate / 10;
@@ -565,6 +591,7 @@ bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = null
     if (t.fmt != HR_FMT_F32 && t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) return false;
     if (t.fmt == HR_FMT_F32 && t.channels == 2) return false;  // the fused kernel reads it as it is
     const void *p = (t.flags & HR_TRACK_DEVICE_PCM) ? t.pcm : dev_or_null;  // staged copies are 256-byte aligned
+    if (fused_s16(ctx, t, p)) return false;                     // likewise
     return (reinterpret_cast<uintptr_t>(p) & 3) == 0;
 }
 size_t plane_floats(const hr_track &t) { return (t.frames * 2 + 63) / 64 * 64; }
@@ -690,6 +717,7 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     if (const char *ab = std::getenv("HR_ABLATE")) ctx->ablate = std::atoi(ab);
     if (const char *sp = std::getenv("HR_FUSED_SPLIT")) ctx->split = std::atoi(sp) != 0;
     if (const char *se = std::getenv("HR_SERIAL_TAIL")) ctx->serial_tail = std::atoi(se) != 0;
+    if (const char *ns = std::getenv("HR_NO_S16_DIRECT")) ctx->no_s16_direct = std::atoi(ns) != 0;
     if (c.stream) ctx->stream = static_cast<hipStream_t>(c.stream);
     else {
         if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return HR_ERR_HIP; }

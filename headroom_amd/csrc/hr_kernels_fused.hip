@@ -54,6 +54,7 @@ typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 //   2 x 1 KiB   carry-table slice of this step / the next one, shared
 constexpr int kPieceLds = 8192, kCoefLds = 9 * 1024, kCarryLds = 1024;
 constexpr int kGroupLds = 4 * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
+constexpr int kFmtF32 = 0, kFmtS16 = 1;      // HR_FMT_F32, HR_FMT_S16 of include/headroom_hip.h
 constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
 
 constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
@@ -118,6 +119,7 @@ __device__ __forceinline__ double fetch_f32s(const TrackDesc &t, int c, int64_t 
         if (t.right_head && i - N < kHalo) return t.right_head[(i - N) * 2 + c];
         return 0.0;
     }
+    if (t.fmt == kFmtS16) return static_cast<double>(static_cast<const int16_t *>(t.pcm)[i * 2 + c]) * (1.0 / 32768.0);
     return static_cast<double>(static_cast<const float *>(t.pcm)[i * 2 + c]);
 }
 
@@ -130,7 +132,7 @@ __device__ __forceinline__ double exact_output(const TrackDesc &t, const double 
     const int64_t pos = row_frame0 + u;
     const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
     double x[kSwrTaps];
-    if (pos >= 15 && pos + 16 < static_cast<int64_t>(t.frames)) {
+    if (t.fmt == kFmtF32 && pos >= 15 && pos + 16 < static_cast<int64_t>(t.frames)) {
         const float *p = static_cast<const float *>(t.pcm) + (pos - 15) * 2 + c;
 #pragma unroll
         for (int k = 0; k < kSwrTaps; k++) x[k] = static_cast<double>(p[2 * k]);
@@ -245,7 +247,18 @@ __device__ __forceinline__ double2 as_double2(uint4v u)
     return c.d;
 }
 
-template <bool DO_KW, bool DO_TP, int MT, bool SMALL>
+// INF: input format, 0 = stereo f32 (8-byte frames, a 128-byte piece per row and step), 1 = stereo s16 (4-byte frames,
+// a 64-byte piece: four lanes per piece in the DMA, four LDS reads per lane, the samples widened to f32 exactly --
+// x * 2^-15 -- as they come out of LDS; everything behind that is the same code).
+// two s16 frames (one dword each: left in the low half) as the float4 the f32 path holds
+__device__ __forceinline__ float4 widen_s16x2(unsigned a, unsigned b)
+{
+    constexpr float sc = 1.0f / 32768.0f;
+    return make_float4(static_cast<float>(static_cast<int>(a << 16) >> 16) * sc, static_cast<float>(static_cast<int>(a) >> 16) * sc,
+                       static_cast<float>(static_cast<int>(b << 16) >> 16) * sc, static_cast<float>(static_cast<int>(b) >> 16) * sc);
+}
+
+template <bool DO_KW, bool DO_TP, int MT, bool SMALL, int INF = 0>
 __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restrict__ tracks,
                                                        const RateDev *__restrict__ rates,
                                                        const FusedItem *__restrict__ items, uint32_t n_items,
@@ -275,7 +288,11 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const int last_row = n_rows > 0 ? n_rows - 1 : 0;
     const int row = lane < n_rows ? lane : last_row;  // idle lanes shadow the last row
     const uint64_t h = it.first_hop + row;
-    const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * 8ull;
+    constexpr unsigned FB = INF ? 4 : 8;        // frame bytes
+    constexpr unsigned PB = 16 * FB;            // piece bytes
+    constexpr int NDMA = INF ? 4 : 8;           // DMA instructions per piece set (64 rows)
+    constexpr int LPP = PB / 16;                // lanes per piece
+    const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * static_cast<unsigned long long>(FB);
     char *lbuf = smem + wave * kPieceLds;
     char *abuf = smem + 4 * kPieceLds;    // [2][9 KiB]: step k reads half k&1
     char *gbuf = abuf + 2 * kCoefLds;     // [2][1 KiB]: step k reads half k&1
@@ -286,16 +303,18 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const int k_short = r.q_n0 < hop ? static_cast<int>(r.q_n0 / 16) : T + 1;
 
     // ---- DMA geometry: instruction j moves LDS slots 8j..8j+7 (one 128-byte piece each, 8 lanes per piece)
-    unsigned dma_off[8];
+    // (s16: instruction j moves slots 16j..16j+15, four lanes per 64-byte piece; position p of row l holds source chunk
+    // p ^ ((l >> 2) & 3), which makes the four reads of sixteen neighbouring lanes cover all banks)
+    unsigned dma_off[NDMA];
 #pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int slot = 8 * j + (lane >> 3);
-        const int chunk = (lane & 7) ^ ((slot >> 1) & 7);
+    for (int j = 0; j < NDMA; j++) {
+        const int slot = (64 / NDMA) * j + lane / LPP;
+        const int chunk = INF ? ((lane & 3) ^ ((slot >> 2) & 3)) : ((lane & 7) ^ ((slot >> 1) & 7));
         const int srow = slot < n_rows ? slot : last_row;
-        dma_off[j] = static_cast<unsigned>(srow) * hop * 8u + static_cast<unsigned>(chunk) * 16u;
+        dma_off[j] = static_cast<unsigned>(srow) * hop * FB + static_cast<unsigned>(chunk) * 16u;
     }
-    const unsigned rd_swz = (lane >> 1) & 7;
-    const char *my_lds = lbuf + lane * 128;
+    const unsigned rd_swz = INF ? (lane >> 2) & 3 : (lane >> 1) & 7;
+    const char *my_lds = lbuf + lane * PB;
 
     // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
     if constexpr (DO_TP) {
@@ -309,10 +328,14 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
     for (int c = 0; c < 2; c++) ks[c] = KState{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     {
-        const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * 8u);
+        const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * FB);
+        const unsigned *rowq = reinterpret_cast<const unsigned *>(rowp);  // s16: one dword per frame
         if (h > 0) {
 #pragma unroll
-            for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(rowp - 32 + 4 * c);
+            for (int c = 0; c < 8; c++) {
+                if constexpr (INF) v[c] = widen_s16x2(rowq[-16 + 2 * c], rowq[-15 + 2 * c]);
+                else v[c] = *reinterpret_cast<const float4 *>(rowp - 32 + 4 * c);
+            }
             ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
             ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
         } else if (t.left_tail) {
@@ -326,9 +349,13 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             // start of the stream: libswresample reflects, x[-j] = x[j]; the K-weighting starts from silence
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                const float2 a = *reinterpret_cast<const float2 *>(rowp + 2 * (16 - 2 * c));
-                const float2 b = *reinterpret_cast<const float2 *>(rowp + 2 * (15 - 2 * c));
-                v[c] = make_float4(a.x, a.y, b.x, b.y);
+                if constexpr (INF) {
+                    v[c] = widen_s16x2(rowq[16 - 2 * c], rowq[15 - 2 * c]);
+                } else {
+                    const float2 a = *reinterpret_cast<const float2 *>(rowp + 2 * (16 - 2 * c));
+                    const float2 b = *reinterpret_cast<const float2 *>(rowp + 2 * (15 - 2 * c));
+                    v[c] = make_float4(a.x, a.y, b.x, b.y);
+                }
             }
         } else {
             // BS.1770: silence in front of the stream
@@ -423,7 +450,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 
     // first piece
 #pragma unroll
-    for (int j = 0; j < 8; j++) dma16(wave_base, dma_off[j], lbuf + j * 1024);
+    for (int j = 0; j < NDMA; j++) dma16(wave_base, dma_off[j], lbuf + j * 1024);
     // carry-table slice of step 0 (1 KiB moved, the first 512 B are the step's; the table is padded)
     if constexpr (DO_KW) {
         if (wave == 0) dma16(gsrc, lane16, gbuf);
@@ -439,15 +466,29 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         // every wave's share of the shared tables has landed, and nobody still reads the halves that this
         // step's DMA is about to overwrite
         __builtin_amdgcn_s_barrier();
+        if constexpr (INF) {
+            uint4v u[4];
 #pragma unroll
-        for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(my_lds + ((c ^ rd_swz) * 16));
+            for (int q = 0; q < 4; q++) u[q] = *reinterpret_cast<const uint4v *>(my_lds + ((q ^ rd_swz) * 16));
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = widen_s16x2(u[c >> 1][(c & 1) * 2], u[c >> 1][(c & 1) * 2 + 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(my_lds + ((c ^ rd_swz) * 16));
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         // the last piece of a hop may be partial (44.1 kHz: 4410 = 275*16 + 10): K-weight its frames one at a
         // time straight from LDS, before the buffer is handed back to the DMA
         if (DO_KW && rem && k == T_full) {
             const char *gk = gbuf + (k & 1) * kCarryLds;
             for (int i = 0; i < rem; i++) {
-                const float2 x = *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8);
+                float2 x;
+                if constexpr (INF) {
+                    const float4 w4 = widen_s16x2(*reinterpret_cast<const unsigned *>(my_lds + (((i >> 2) ^ rd_swz) * 16) + (i & 3) * 4), 0u);
+                    x = make_float2(w4.x, w4.y);
+                } else {
+                    x = *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8);
+                }
                 if constexpr (!SHORT) {
                     const G4 g4 = lds_g4(gk + i * 32);
                     kw_sample(ks[0], kc, x.x, g4);
@@ -461,9 +502,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         }
         // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
         if (k < T && !(dbg & 16)) {
-            const char *src = wave_base + ((dbg & 32) ? 0 : static_cast<size_t>(k + 1) * 128);  // dbg 32: re-read piece 0 (cache hits)
+            const char *src = wave_base + ((dbg & 32) ? 0 : static_cast<size_t>(k + 1) * PB);  // dbg 32: re-read piece 0 (cache hits)
 #pragma unroll
-            for (int j = 0; j < 8; j++) dma16(src, dma_off[j], lbuf + j * 1024);
+            for (int j = 0; j < NDMA; j++) dma16(src, dma_off[j], lbuf + j * 1024);
             if constexpr (DO_KW) {
                 if (wave == 0) dma16(gsrc + static_cast<size_t>(k + 1) * 512, lane16, gbuf + ((k + 1) & 1) * kCarryLds);
             }
@@ -1214,14 +1255,14 @@ __global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__re
 
 size_t fused_cand_bytes(uint32_t n_items) { return static_cast<size_t>(n_items) * kCandCap * sizeof(uint2); }
 
-template <bool DO_KW, bool DO_TP>
+template <bool DO_KW, bool DO_TP, int INF = 0>
 static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStream_t st, const TrackDesc *tracks,
                          const RateDev *rates, const FusedItem *items, uint32_t n_items, HopRec *recs, uint2 *cands,
                          const FusedScratch &fs, unsigned long long *peaks, int dbg)
 {
 #define HR_FUSED_CASE(MT, SMALL)                                                                                      \
-    k_fused_f32s<DO_KW, DO_TP, MT, SMALL><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands,     \
-                                                                     fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg)
+    k_fused_f32s<DO_KW, DO_TP, MT, SMALL, INF><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, \
+                                                                          fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg)
     if constexpr (!DO_TP) {
         HR_FUSED_CASE(1, false);
     } else {
@@ -1284,6 +1325,11 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
         case 4: launch_split_case<3, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
         default: launch_split_case<3, true>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
         }
+        k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
+        return;
+    }
+    if (variant == 5) {  // full pass on stereo s16
+        launch_class<true, true, 1>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
         k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
         return;
     }

@@ -396,7 +396,7 @@ def test_analyze_stream_sharded_in_process(oracle, meters, gate):
 
 @pytest.mark.parametrize("fs", [44100, 48000])
 def test_integer_stereo_tracks_take_the_fused_kernel(oracle, meters, fs):
-    """s16 / s24 stereo is widened to f32 on the device (exactly) and measured by the fused kernel: same numbers
+    """s24 stereo is widened to f32 on the device (exactly), s16 stereo read directly, and measured by the fused kernel: same numbers
     as the generic kernels and the oracle, from host and device buffers, also when the widened copies do not fit
     one group."""
     import torch
@@ -579,3 +579,36 @@ def test_isolated_peaks_between_output_positions(oracle, meters, fs, engine):
         assert got["peak_per_ch"][0] < float(np.abs(pcm[:, 0]).max())
     else:
         assert got["peak_per_ch"][0] >= float(np.abs(pcm[:, 0]).max())
+
+
+@pytest.mark.parametrize("tp", ["swr192k", "bs1770", "sample"])
+@pytest.mark.parametrize("fs", [44100, 48000, 96000, 88200])
+def test_stereo_s16_is_read_directly_by_the_fused_kernel(oracle, meters, fs, tp, monkeypatch):
+    """Stereo s16 takes the fused kernel's full pass as it is (64-byte pieces, widened to f32 as they leave LDS); with
+    HR_NO_S16_DIRECT=1, and in the sample-peak mode, it is widened into f32 planes first.  Same numbers either way,
+    and the oracle's: noise with a quiet start, a full-scale sine (candidate lists overflow), a clipped signal, an
+    odd start (device pointer 16 but not 128 bytes aligned), a track of two hops and a bit."""
+    import torch
+    n = fs * 7 + 555
+    noise = signals.seeded_noise(5 + fs, n, 2, -9.0)
+    noise[: fs] *= 0.01
+    t = np.arange(n) / fs
+    sine = np.stack([np.sin(2 * np.pi * 997.0 * t), np.sin(2 * np.pi * 3001.0 * t + 1.0)], axis=1) * 0.999
+    clipped = np.clip(signals.seeded_noise(6 + fs, n, 2, -3.0) * 3.0, -1.0, 1.0) * 0.9
+    cases = [signals.to_s16(x) for x in (noise, sine, clipped, noise[: fs // 5 + 99])]
+    dev = torch.from_numpy(np.concatenate([np.zeros((4, 2), np.int16), cases[0]])).cuda()  # 16 bytes in: odd start
+    odd = hr.TrackSpec(dev.data_ptr() + 16, fs, channels=2, fmt=hr.FMT_S16, frames=len(cases[0]))
+    refs = [oracle.measure(x, fs, gate_mode=0, tp_mode=TPS[tp]) for x in cases]
+    direct = meters("ebur128", tp).analyze_batch([hr.TrackSpec(x, fs) for x in cases] + [odd])
+    monkeypatch.setenv("HR_NO_S16_DIRECT", "1")
+    m = hr.Meter(device=0, tp_mode=TPS[tp])
+    try:
+        widened = m.analyze_batch([hr.TrackSpec(x, fs) for x in cases] + [odd])
+    finally:
+        m.close()
+    for g, w, ref in zip(direct, widened, refs + [refs[0]]):
+        assert g["status"] == 0 and g["n_blocks"] == ref["n_blocks"] and g["n_gated"] == ref["n_gated"]
+        assert g["peak_per_ch"] == w["peak_per_ch"] == ref["peak_per_ch"]
+        assert g["integrated_lufs"] == w["integrated_lufs"] or (math.isnan(g["integrated_lufs"]) and math.isnan(w["integrated_lufs"]))
+        if math.isfinite(ref["integrated_lufs"]):
+            assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
