@@ -57,8 +57,8 @@ def main():
     ap.add_argument("--engine", type=int, default=0)
     ap.add_argument("--tp-mode", choices=["swr192k", "bs1770", "sample"], default="swr192k",
                     help="true-peak interpolator (swr192k = FFmpeg's, the BASELINE workload; the others are side figures)")
-    ap.add_argument("--pcm-format", choices=["f32", "s16"], default="f32",
-                    help="f32 is the BASELINE workload; s16 measures the widening path (a side figure, labelled as such)")
+    ap.add_argument("--pcm-format", choices=["f32", "s16", "s24"], default="f32",
+                    help="f32 is the BASELINE workload; s16 / s24 measure the integer stereo input of the fused kernel (side figures, labelled as such)")
     ap.add_argument("--workload", choices=["config2", "config3", "config4", "config5"], default="config2",
                     help="config2 = the BASELINE bench workload; config3 = one GPU's share of the 10,000-track 48 kHz batch "
                          "(1,250 tracks, 86.4 GB; a side figure); config4 = 96 kHz 24-bit 5.1 tracks (a side figure: split into "
@@ -120,6 +120,14 @@ def main():
         torch.cuda.synchronize()
         specs = [hr.TrackSpec(pcm16[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_S16, frames=frames) for i in range(n_tracks)]
         bytes_per_step = n_tracks * frames * CH * 2
+    elif args.pcm_format == "s24":
+        pcm24 = torch.empty((n_tracks, frames * CH * 3), dtype=torch.uint8, device=dev)
+        for i in range(n_tracks):
+            q = torch.clamp(torch.round(pcm[i][:frames] * 8388608.0), -8388608, 8388607).to(torch.int32).reshape(-1)
+            pcm24[i] = torch.stack([q & 0xFF, (q >> 8) & 0xFF, (q >> 16) & 0xFF], dim=1).to(torch.uint8).reshape(-1)
+        torch.cuda.synchronize()
+        specs = [hr.TrackSpec(pcm24[i].data_ptr(), FS, channels=CH, fmt=hr.FMT_S24, frames=frames) for i in range(n_tracks)]
+        bytes_per_step = n_tracks * frames * CH * 3
     else:
         specs = [hr.TrackSpec(pcm[i].data_ptr() + boff, FS, channels=CH, fmt=hr.FMT_F32, frames=frames) for i in range(n_tracks)]
         bytes_per_step = n_tracks * frames * CH * 4

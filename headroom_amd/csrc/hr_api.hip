@@ -255,12 +255,12 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0), fsp(nt, 0);  // fused K-weighting / + true-peak screen / + sample peak
     for (size_t i = 0; i < nt; i++) {
         const TrackDesc &d = g.descs[i];
-        bool ok = d.role != 1 && ctx->cfg.engine != 1 && (d.fmt == HR_FMT_F32 || d.fmt == HR_FMT_S16) && d.ch == 2 && d.n_hops >= 2 &&
+        bool ok = d.role != 1 && ctx->cfg.engine != 1 && (d.fmt == HR_FMT_F32 || d.fmt == HR_FMT_S16 || (d.fmt == HR_FMT_S24 && d.hop % 2 == 0)) && d.ch == 2 && d.n_hops >= 2 &&
                   d.hop >= 64 && (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
         const bool tp_ok = do_peaks && (ctx->cfg.tp_mode == HR_TP_SWR192K || ctx->cfg.tp_mode == HR_TP_BS1770) &&
                            ctx->rates_h[d.rate_idx].tp_atab != nullptr;
         // stereo s16 is read as it is by the full pass only (K-weighting + true-peak screen); see fused_s16()
-        if (d.fmt == HR_FMT_S16 && !tp_ok) ok = false;
+        if (d.fmt != HR_FMT_F32 && (!tp_ok || ctx->no_s16_direct)) ok = false;
         fkw[i] = ok;
         ftp[i] = ok && tp_ok;
         // the peak is the plain sample peak: HR_TP_SAMPLE, 192 kHz input (nothing to interpolate)
@@ -270,8 +270,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
-    // class 6 = K-weight only, class 7 = K-weight + sample peak, classes 8..13 = classes 0..5 reading stereo s16
-    constexpr int kFusedClasses = 14;
+    // class 6 = K-weight only, class 7 = K-weight + sample peak, classes 8..13 / 14..19 = classes 0..5 reading stereo s16 / s24
+    constexpr int kFusedClasses = 20;
     size_t class_off[kFusedClasses + 1];
     // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
     // mixes rates: every (class, rate) run is padded to a multiple of 4 with n_rows == 0 copies of its last item.
@@ -282,7 +282,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             for (size_t i = 0; i < nt; i++) {
                 if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri)) continue;
                 const RateDev &rd = ctx->rates_h[ri];
-                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : 0) : fsp[i] ? 7 : 6;
+                const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
                 const uint64_t interior = g.descs[i].n_hops - 1;
                 for (uint64_t h = 0; h < interior; h += 64)
@@ -318,8 +318,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         hop_span[f].n = items.size() - hop_span[f].off;
     }
     // last hop of the fused tracks (all f32): one lane per (track, channel)
-    Span tail_span[2];  // f32, s16
-    for (int f = 0; f < 2; f++) {
+    Span tail_span[3];  // f32, s16, s24
+    for (int f = 0; f < 3; f++) {
         tail_span[f].off = items.size();
         for (size_t i = 0; i < nt; i++)
             if (fkw[i] && g.fmts[i] == f)
@@ -382,7 +382,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
     for (int f = 0; f < 5; f++)
         launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), tail_st);
-    for (int f = 0; f < 2; f++)
+    for (int f = 0; f < 3; f++)
         launch_hop_zero_state_list(f, dt, dr, di + tail_span[f].off, static_cast<uint32_t>(tail_span[f].n), ctx->recs.as<HopRec>(), tail_st);
     if (do_peaks) {
         for (int f = 0; f < 5; f++)
@@ -409,8 +409,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             const bool tp = cls < 6;
             launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
                               ctx->peaks.as<unsigned long long>(),
-                              cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
-                              cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
+                              cls >= 14 ? 6 : cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
+                              cls >= 14 ? cls - 14 : cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
@@ -533,8 +533,8 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     HIPCHK(hipStreamSynchronize(st));
     std::vector<WorkItem> &items = ctx->h_ovf_items;
     items.clear();
-    size_t fmt_end[2];  // f32 items first, then s16
-    for (int f = 0; f < 2; f++) {
+    size_t fmt_end[3];  // f32 items first, then s16, then s24
+    for (int f = 0; f < 3; f++) {
         for (size_t i = 0; i < nt; i++) {
             if (!ctx->h_ftp[i] || !ovf[i] || g.fmts[i] != f) continue;
             const uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
@@ -559,8 +559,8 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     // the last item of a track may reach a little past `end`: those positions are redone too, harmlessly
     int rc = upload(ctx->ovf_items, items.data(), items.size() * sizeof(WorkItem), st);
     if (rc) return rc;
-    for (int f = 0; f < 2; f++) {
-        const size_t b = f ? fmt_end[0] : 0;
+    for (int f = 0; f < 3; f++) {
+        const size_t b = f ? fmt_end[f - 1] : 0;
         launch_true_peak_generic(f, HR_TP_SWR192K, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(),
                                  ctx->ovf_items.as<WorkItem>() + b, static_cast<uint32_t>(fmt_end[f] - b),
                                  kPeakSpan, ctx->peaks.as<unsigned long long>(), st);
@@ -572,11 +572,12 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
 // Every f32 / s16 / s24 track that is not already stereo f32 is split on the device into stereo f32 planes (exactly)
 // so that it takes the fused kernel: mono, 5.1, 7.1, integer stereo.  The generic kernels, one thread per hop, are two
 // orders of magnitude slower.  s32 / f64 samples do not fit f32 and stay generic.
-// Stereo s16 is read directly by the fused kernel's full pass (K-weighting + true-peak screen): needs a true-peak mode
+// Stereo s16 / s24 is read directly by the fused kernel's full pass (K-weighting + true-peak screen): needs a true-peak mode
 // with a tile table at this rate and a 16-byte aligned buffer.  (Other cases are widened into f32 planes first.)
 bool fused_s16(const hr_ctx *ctx, const hr_track &t, const void *dev)
 {
-    if (t.fmt != HR_FMT_S16 || t.channels != 2 || ctx->no_s16_direct) return false;
+    if ((t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) || t.channels != 2 || ctx->no_s16_direct) return false;
+    if (t.fmt == HR_FMT_S24 && (t.sample_rate / 10) % 2) return false;  // its rows must start on a dword
     if (ctx->cfg.tp_mode != HR_TP_SWR192K && ctx->cfg.tp_mode != HR_TP_BS1770) return false;
     const RateTables *rt = rate_tables(t.sample_rate);
     if (!rt) return false;

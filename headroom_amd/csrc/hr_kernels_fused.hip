@@ -54,7 +54,7 @@ typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 //   2 x 1 KiB   carry-table slice of this step / the next one, shared
 constexpr int kPieceLds = 8192, kCoefLds = 9 * 1024, kCarryLds = 1024;
 constexpr int kGroupLds = 4 * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
-constexpr int kFmtF32 = 0, kFmtS16 = 1;      // HR_FMT_F32, HR_FMT_S16 of include/headroom_hip.h
+constexpr int kFmtF32 = 0, kFmtS16 = 1, kFmtS24 = 2;  // HR_FMT_F32, HR_FMT_S16, HR_FMT_S24 of include/headroom_hip.h
 constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
 
 constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
@@ -120,6 +120,11 @@ __device__ __forceinline__ double fetch_f32s(const TrackDesc &t, int c, int64_t 
         return 0.0;
     }
     if (t.fmt == kFmtS16) return static_cast<double>(static_cast<const int16_t *>(t.pcm)[i * 2 + c]) * (1.0 / 32768.0);
+    if (t.fmt == kFmtS24) {
+        const uint8_t *b = static_cast<const uint8_t *>(t.pcm) + (i * 2 + c) * 3;
+        const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 8 | static_cast<uint32_t>(b[1]) << 16 | static_cast<uint32_t>(b[2]) << 24) >> 8;
+        return static_cast<double>(x) * (1.0 / 8388608.0);
+    }
     return static_cast<double>(static_cast<const float *>(t.pcm)[i * 2 + c]);
 }
 
@@ -258,6 +263,25 @@ __device__ __forceinline__ float4 widen_s16x2(unsigned a, unsigned b)
                        static_cast<float>(static_cast<int>(b << 16) >> 16) * sc, static_cast<float>(static_cast<int>(b) >> 16) * sc);
 }
 
+// INF 2 = stereo s24 (packed, 6-byte frames, a 96-byte piece: six lanes per piece in the DMA, six LDS reads per lane,
+// every sample cut out of the lane's 24 dwords by compile-time shifts and widened exactly, x * 2^-23).
+// one packed s24 stereo frame from memory (prologue only)
+__device__ __forceinline__ float2 s24_frame(const uint8_t *p)
+{
+    constexpr float sc = 1.0f / 8388608.0f;
+    const int32_t l = static_cast<int32_t>(static_cast<uint32_t>(p[0]) << 8 | static_cast<uint32_t>(p[1]) << 16 | static_cast<uint32_t>(p[2]) << 24) >> 8;
+    const int32_t r = static_cast<int32_t>(static_cast<uint32_t>(p[3]) << 8 | static_cast<uint32_t>(p[4]) << 16 | static_cast<uint32_t>(p[5]) << 24) >> 8;
+    return make_float2(static_cast<float>(l) * sc, static_cast<float>(r) * sc);
+}
+// sample s (0..31: frame s/2, channel s&1) of a 16-frame s24 piece held as 24 dwords (+1 so that w[d+1] exists)
+template <int S>
+__device__ __forceinline__ float s24_sample(const unsigned (&w)[25])
+{
+    constexpr int d = (3 * S) >> 2, sh = ((3 * S) & 3) * 8;
+    const unsigned bits = sh <= 8 ? w[d] >> sh : __funnelshift_r(w[d], w[d + 1], sh);
+    return static_cast<float>(static_cast<int>(bits << 8) >> 8) * (1.0f / 8388608.0f);
+}
+
 template <bool DO_KW, bool DO_TP, int MT, bool SMALL, int INF = 0>
 __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restrict__ tracks,
                                                        const RateDev *__restrict__ rates,
@@ -288,9 +312,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const int last_row = n_rows > 0 ? n_rows - 1 : 0;
     const int row = lane < n_rows ? lane : last_row;  // idle lanes shadow the last row
     const uint64_t h = it.first_hop + row;
-    constexpr unsigned FB = INF ? 4 : 8;        // frame bytes
+    constexpr unsigned FB = INF == 1 ? 4 : INF == 2 ? 6 : 8;  // frame bytes
     constexpr unsigned PB = 16 * FB;            // piece bytes
-    constexpr int NDMA = INF ? 4 : 8;           // DMA instructions per piece set (64 rows)
+    constexpr int NDMA = PB / 16;               // DMA instructions per piece set (64 rows): 8, 4 or 6
     constexpr int LPP = PB / 16;                // lanes per piece
     const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * static_cast<unsigned long long>(FB);
     char *lbuf = smem + wave * kPieceLds;
@@ -308,12 +332,17 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     unsigned dma_off[NDMA];
 #pragma unroll
     for (int j = 0; j < NDMA; j++) {
-        const int slot = (64 / NDMA) * j + lane / LPP;
-        const int chunk = INF ? ((lane & 3) ^ ((slot >> 2) & 3)) : ((lane & 7) ^ ((slot >> 1) & 7));
+        // (s24: 384 lane slots = 64 rows x 6 chunks, rows do not end with the instruction; position p of row l holds
+        // source chunk (p - ((l >> 3) & 1)) mod 6: rows l and l + 8, whose 96-byte images start in the same bank, are a
+        // chunk apart)
+        const int gi = 64 * j + lane;
+        const int slot = INF == 2 ? gi / 6 : (64 / NDMA) * j + lane / LPP;
+        const int chunk = INF == 2 ? (gi % 6 + 6 - ((slot >> 3) & 1)) % 6
+                        : INF == 1 ? ((lane & 3) ^ ((slot >> 2) & 3)) : ((lane & 7) ^ ((slot >> 1) & 7));
         const int srow = slot < n_rows ? slot : last_row;
         dma_off[j] = static_cast<unsigned>(srow) * hop * FB + static_cast<unsigned>(chunk) * 16u;
     }
-    const unsigned rd_swz = INF ? (lane >> 2) & 3 : (lane >> 1) & 7;
+    const unsigned rd_swz = INF == 2 ? (lane >> 3) & 1 : INF == 1 ? (lane >> 2) & 3 : (lane >> 1) & 7;  // s24: a rotation, not an xor
     const char *my_lds = lbuf + lane * PB;
 
     // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
@@ -330,11 +359,18 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     {
         const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * FB);
         const unsigned *rowq = reinterpret_cast<const unsigned *>(rowp);  // s16: one dword per frame
+        const uint8_t *rowb = reinterpret_cast<const uint8_t *>(rowp);    // s24: six bytes per frame
         if (h > 0) {
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                if constexpr (INF) v[c] = widen_s16x2(rowq[-16 + 2 * c], rowq[-15 + 2 * c]);
-                else v[c] = *reinterpret_cast<const float4 *>(rowp - 32 + 4 * c);
+                if constexpr (INF == 2) {
+                    const float2 a = s24_frame(rowb + (-16 + 2 * c) * 6), b = s24_frame(rowb + (-15 + 2 * c) * 6);
+                    v[c] = make_float4(a.x, a.y, b.x, b.y);
+                } else if constexpr (INF == 1) {
+                    v[c] = widen_s16x2(rowq[-16 + 2 * c], rowq[-15 + 2 * c]);
+                } else {
+                    v[c] = *reinterpret_cast<const float4 *>(rowp - 32 + 4 * c);
+                }
             }
             ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
             ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
@@ -349,7 +385,10 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             // start of the stream: libswresample reflects, x[-j] = x[j]; the K-weighting starts from silence
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                if constexpr (INF) {
+                if constexpr (INF == 2) {
+                    const float2 a = s24_frame(rowb + (16 - 2 * c) * 6), b = s24_frame(rowb + (15 - 2 * c) * 6);
+                    v[c] = make_float4(a.x, a.y, b.x, b.y);
+                } else if constexpr (INF == 1) {
                     v[c] = widen_s16x2(rowq[16 - 2 * c], rowq[15 - 2 * c]);
                 } else {
                     const float2 a = *reinterpret_cast<const float2 *>(rowp + 2 * (16 - 2 * c));
@@ -466,7 +505,24 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         // every wave's share of the shared tables has landed, and nobody still reads the halves that this
         // step's DMA is about to overwrite
         __builtin_amdgcn_s_barrier();
-        if constexpr (INF) {
+        if constexpr (INF == 2) {
+            unsigned w[25];
+            const char *rot = my_lds + rd_swz * 16;  // source chunk q sits at position (q + rd_swz) mod 6
+#pragma unroll
+            for (int q = 0; q < 6; q++) {
+                const uint4v u = *reinterpret_cast<const uint4v *>(q < 5 ? rot + q * 16 : rot + 80 - rd_swz * 96);
+                w[4 * q] = u[0]; w[4 * q + 1] = u[1]; w[4 * q + 2] = u[2]; w[4 * q + 3] = u[3];
+            }
+            w[24] = 0;
+            v[0] = make_float4(s24_sample<0>(w), s24_sample<1>(w), s24_sample<2>(w), s24_sample<3>(w));
+            v[1] = make_float4(s24_sample<4>(w), s24_sample<5>(w), s24_sample<6>(w), s24_sample<7>(w));
+            v[2] = make_float4(s24_sample<8>(w), s24_sample<9>(w), s24_sample<10>(w), s24_sample<11>(w));
+            v[3] = make_float4(s24_sample<12>(w), s24_sample<13>(w), s24_sample<14>(w), s24_sample<15>(w));
+            v[4] = make_float4(s24_sample<16>(w), s24_sample<17>(w), s24_sample<18>(w), s24_sample<19>(w));
+            v[5] = make_float4(s24_sample<20>(w), s24_sample<21>(w), s24_sample<22>(w), s24_sample<23>(w));
+            v[6] = make_float4(s24_sample<24>(w), s24_sample<25>(w), s24_sample<26>(w), s24_sample<27>(w));
+            v[7] = make_float4(s24_sample<28>(w), s24_sample<29>(w), s24_sample<30>(w), s24_sample<31>(w));
+        } else if constexpr (INF == 1) {
             uint4v u[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) u[q] = *reinterpret_cast<const uint4v *>(my_lds + ((q ^ rd_swz) * 16));
@@ -483,7 +539,15 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             const char *gk = gbuf + (k & 1) * kCarryLds;
             for (int i = 0; i < rem; i++) {
                 float2 x;
-                if constexpr (INF) {
+                if constexpr (INF == 2) {
+                    uint8_t fb[6];
+#pragma unroll
+                    for (int bb = 0; bb < 6; bb++) {
+                        const unsigned byte = 6u * i + bb, pos = ((byte >> 4) + rd_swz) % 6u;
+                        fb[bb] = *reinterpret_cast<const uint8_t *>(my_lds + pos * 16 + (byte & 15));
+                    }
+                    x = s24_frame(fb);
+                } else if constexpr (INF == 1) {
                     const float4 w4 = widen_s16x2(*reinterpret_cast<const unsigned *>(my_lds + (((i >> 2) ^ rd_swz) * 16) + (i & 3) * 4), 0u);
                     x = make_float2(w4.x, w4.y);
                 } else {
@@ -1328,8 +1392,9 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
         k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
         return;
     }
-    if (variant == 5) {  // full pass on stereo s16
-        launch_class<true, true, 1>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
+    if (variant == 5 || variant == 6) {  // full pass on stereo s16 / s24
+        if (variant == 5) launch_class<true, true, 1>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
+        else launch_class<true, true, 2>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
         k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
         return;
     }

@@ -581,13 +581,14 @@ def test_isolated_peaks_between_output_positions(oracle, meters, fs, engine):
         assert got["peak_per_ch"][0] >= float(np.abs(pcm[:, 0]).max())
 
 
+@pytest.mark.parametrize("kind", ["s16", "s24"])
 @pytest.mark.parametrize("tp", ["swr192k", "bs1770", "sample"])
 @pytest.mark.parametrize("fs", [44100, 48000, 96000, 88200])
-def test_stereo_s16_is_read_directly_by_the_fused_kernel(oracle, meters, fs, tp, monkeypatch):
-    """Stereo s16 takes the fused kernel's full pass as it is (64-byte pieces, widened to f32 as they leave LDS); with
-    HR_NO_S16_DIRECT=1, and in the sample-peak mode, it is widened into f32 planes first.  Same numbers either way,
-    and the oracle's: noise with a quiet start, a full-scale sine (candidate lists overflow), a clipped signal, an
-    odd start (device pointer 16 but not 128 bytes aligned), a track of two hops and a bit."""
+def test_integer_stereo_is_read_directly_by_the_fused_kernel(oracle, meters, fs, tp, kind, monkeypatch):
+    """Stereo s16 / s24 takes the fused kernel's full pass as it is (64- / 96-byte pieces, widened to f32 as they leave
+    LDS); with HR_NO_S16_DIRECT=1, and in the sample-peak mode, it is widened into f32 planes first.  Same numbers
+    either way, and the oracle's: noise with a quiet start, a full-scale sine (candidate lists overflow), a clipped
+    signal, an odd start (device pointer 16 but not 128 bytes aligned), a track of two hops and a bit."""
     import torch
     n = fs * 7 + 555
     noise = signals.seeded_noise(5 + fs, n, 2, -9.0)
@@ -595,15 +596,20 @@ def test_stereo_s16_is_read_directly_by_the_fused_kernel(oracle, meters, fs, tp,
     t = np.arange(n) / fs
     sine = np.stack([np.sin(2 * np.pi * 997.0 * t), np.sin(2 * np.pi * 3001.0 * t + 1.0)], axis=1) * 0.999
     clipped = np.clip(signals.seeded_noise(6 + fs, n, 2, -3.0) * 3.0, -1.0, 1.0) * 0.9
-    cases = [signals.to_s16(x) for x in (noise, sine, clipped, noise[: fs // 5 + 99])]
-    dev = torch.from_numpy(np.concatenate([np.zeros((4, 2), np.int16), cases[0]])).cuda()  # 16 bytes in: odd start
-    odd = hr.TrackSpec(dev.data_ptr() + 16, fs, channels=2, fmt=hr.FMT_S16, frames=len(cases[0]))
-    refs = [oracle.measure(x, fs, gate_mode=0, tp_mode=TPS[tp]) for x in cases]
-    direct = meters("ebur128", tp).analyze_batch([hr.TrackSpec(x, fs) for x in cases] + [odd])
+    sigs = (noise, sine, clipped, noise[: fs // 5 + 99])
+    if kind == "s16":
+        cases, kw, fmt = [signals.to_s16(x) for x in sigs], {}, hr.FMT_S16
+        dev = torch.from_numpy(np.concatenate([np.zeros((4, 2), np.int16), cases[0]])).cuda()  # 16 bytes in: odd start
+    else:
+        cases, kw, fmt = [signals.to_s24_bytes(x) for x in sigs], {"channels": 2, "fmt": hr.FMT_S24}, hr.FMT_S24
+        dev = torch.from_numpy(np.concatenate([np.zeros(16, np.uint8), cases[0].reshape(-1)])).cuda()
+    odd = hr.TrackSpec(dev.data_ptr() + 16, fs, channels=2, fmt=fmt, frames=len(sigs[0]))
+    refs = [oracle.measure(x, fs, gate_mode=0, tp_mode=TPS[tp], **kw) for x in cases]
+    direct = meters("ebur128", tp).analyze_batch([hr.TrackSpec(x, fs, **kw) for x in cases] + [odd])
     monkeypatch.setenv("HR_NO_S16_DIRECT", "1")
     m = hr.Meter(device=0, tp_mode=TPS[tp])
     try:
-        widened = m.analyze_batch([hr.TrackSpec(x, fs) for x in cases] + [odd])
+        widened = m.analyze_batch([hr.TrackSpec(x, fs, **kw) for x in cases] + [odd])
     finally:
         m.close()
     for g, w, ref in zip(direct, widened, refs + [refs[0]]):
