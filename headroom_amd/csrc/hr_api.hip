@@ -609,13 +609,17 @@ int add_track(hr_ctx *ctx, Group &g, const hr_track &t, const void *dev, float *
     add_desc(g, t, dev, ri, true, true, false, t.frames, ctx->cfg.tp_mode);
     if (!do_split) return own;
     const size_t pf = plane_floats(t);
-    launch_split_planes(t.fmt, dev, plane_mem, t.frames, t.channels, pf, ctx->stream);
+    // integer tracks keep their sample format in the planes where the fused kernel reads stereo s16 / s24 directly
+    hr_track as_stereo = t;
+    as_stereo.channels = 2;
+    const bool keep = fused_s16(ctx, as_stereo, plane_mem);
+    launch_split_planes(t.fmt, dev, plane_mem, t.frames, t.channels, pf, keep, ctx->stream);
     g.descs[own].role = 1;
     g.descs[own].first_plane = static_cast<uint32_t>(own + 1);
     g.parents.push_back(static_cast<uint32_t>(own));
     hr_track pt = t;
     pt.channels = 2;
-    pt.fmt = HR_FMT_F32;
+    pt.fmt = keep ? t.fmt : HR_FMT_F32;
     pt.ch_weight = nullptr;
     for (int p = 0; p < (t.channels + 1) / 2; p++) {
         add_desc(g, pt, plane_mem + p * pf, ri, true, true, false, t.frames, ctx->cfg.tp_mode);

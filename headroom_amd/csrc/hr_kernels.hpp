@@ -72,7 +72,7 @@ void synth_params(uint64_t seed, uint32_t fs, uint64_t frames, SynthPar *p);
 // interleaved f32 / s16 / s24 (fmt 0 / 1 / 2; src dword aligned) of any channel count -> (channels+1)/2 stereo f32
 // planes, plane p at dst + p*plane_floats (16-byte aligned), exact
 void launch_split_planes(int fmt, const void *src, float *dst, uint64_t frames, uint32_t channels, uint64_t plane_floats,
-                         hipStream_t st);
+                         bool keep_format, hipStream_t st);
 void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channels, uint64_t frames, hipStream_t st);
 
 }  // namespace hr

@@ -100,7 +100,10 @@ void launch_synth(float *out, uint64_t seed, const SynthPar &p, uint32_t channel
 // One workgroup moves 256 frames: the interleaved bytes come in as coalesced dwords through LDS (a 5.1 s24 frame is
 // 18 bytes: no lane-aligned view of it exists), the planes go out as one float2 per lane.
 // ---------------------------------------------------------------------------------------------
-template <int FMT>  // 0 f32, 1 s16, 2 s24 (HR_FMT_*)
+// KEEP (s16 / s24 input): the planes keep the input's sample format -- interleaved stereo s16 / packed s24, which the
+// fused kernel reads directly -- instead of f32: 4 / 6 bytes written and read again per frame and plane instead of 8.
+// The plane stride stays plane_floats * 4 bytes.
+template <int FMT, bool KEEP = false>  // 0 f32, 1 s16, 2 s24 (HR_FMT_*)
 __global__ void __launch_bounds__(256) k_split_planes(const uint8_t *__restrict__ src, float *__restrict__ dst, uint64_t frames,
                                                       uint32_t channels, uint64_t plane_floats)
 {
@@ -120,6 +123,12 @@ __global__ void __launch_bounds__(256) k_split_planes(const uint8_t *__restrict_
         if (f < frames) {
             const uint8_t *fp = reinterpret_cast<const uint8_t *>(lds) + threadIdx.x * fb;
             for (uint32_t p = 0; p < planes; p++) {
+                if constexpr (KEEP) {
+                    uint8_t *o = reinterpret_cast<uint8_t *>(dst + p * plane_floats) + f * (2 * B);
+                    for (uint32_t j = 0; j < 2; j++)
+                        for (uint32_t k = 0; k < B; k++) o[j * B + k] = (2 * p + j < channels) ? fp[(2 * p + j) * B + k] : uint8_t(0);
+                    continue;
+                }
                 float v[2] = {0.0f, 0.0f};
 #pragma unroll
                 for (uint32_t j = 0; j < 2; j++) {
@@ -150,7 +159,7 @@ __global__ void __launch_bounds__(256) k_split_planes(const uint8_t *__restrict_
 // frames per lane through LDS (the lane's chunk is CH*B dwords; an even chunk length is padded by one dword so that the
 // lanes spread over the banks), every sample cut out of its dword(s) by compile-time shifts, 32 bytes per lane and plane
 // out.  Needs a 16-byte aligned source; launch_split_planes sends the ragged end and anything else to the kernel above.
-template <int FMT, int CH>
+template <int FMT, int CH, bool KEEP = false>
 __global__ void __launch_bounds__(256) k_split_planes_wide(const uint8_t *__restrict__ src, float *__restrict__ dst, uint64_t n_blocks,
                                                            uint64_t plane_floats)
 {
@@ -183,6 +192,31 @@ __global__ void __launch_bounds__(256) k_split_planes_wide(const uint8_t *__rest
         const uint64_t f = blk * 1024 + threadIdx.x * 4;
 #pragma unroll
         for (int p = 0; p < PLANES; p++) {
+            if constexpr (KEEP && FMT != 0) {
+                // the four frames' two samples as raw 16- / 24-bit fields, packed again: 16 / 24 bytes per lane and plane
+                uint32_t q[8];
+#pragma unroll
+                for (int i = 0; i < 4; i++)
+#pragma unroll
+                    for (int j = 0; j < 2; j++) {
+                        const int c = 2 * p + j;
+                        if (c >= CH) { q[2 * i + j] = 0; continue; }
+                        const int byte = (i * CH + c) * B, d = byte >> 2, sh = (byte & 3) * 8;
+                        if constexpr (FMT == 1) q[2 * i + j] = (w[d] >> sh) & 0xffffu;
+                        else q[2 * i + j] = (sh <= 8 ? w[d] >> sh : __funnelshift_r(w[d], w[d + 1], sh)) & 0xffffffu;
+                    }
+                uint8_t *o = reinterpret_cast<uint8_t *>(dst + p * plane_floats) + f * (2 * B);
+                if constexpr (FMT == 1) {
+                    *reinterpret_cast<uint4v *>(o) = uint4v{q[0] | q[1] << 16, q[2] | q[3] << 16, q[4] | q[5] << 16, q[6] | q[7] << 16};
+                } else {
+                    typedef unsigned uint2v __attribute__((ext_vector_type(2)));
+                    uint2v *o2 = reinterpret_cast<uint2v *>(o);  // 24 bytes per lane: 8-byte aligned
+                    o2[0] = uint2v{q[0] | q[1] << 24, q[1] >> 8 | q[2] << 16};
+                    o2[1] = uint2v{q[2] >> 16 | q[3] << 8, q[4] | q[5] << 24};
+                    o2[2] = uint2v{q[5] >> 8 | q[6] << 16, q[6] >> 16 | q[7] << 8};
+                }
+                continue;
+            }
             float v[4][2];
 #pragma unroll
             for (int i = 0; i < 4; i++)
@@ -207,12 +241,12 @@ __global__ void __launch_bounds__(256) k_split_planes_wide(const uint8_t *__rest
     }
 }
 
-template <int FMT>
+template <int FMT, bool KEEP = false>
 static bool launch_split_wide(const uint8_t *s, float *dst, uint64_t n_blocks, uint32_t channels, uint64_t plane_floats, hipStream_t st)
 {
     const dim3 grid(static_cast<uint32_t>(n_blocks < 256 * 16 ? n_blocks : 256 * 16)), block(256);
     switch (channels) {
-#define HR_SPLIT_CASE(C) case C: k_split_planes_wide<FMT, C><<<grid, block, 0, st>>>(s, dst, n_blocks, plane_floats); return true
+#define HR_SPLIT_CASE(C) case C: k_split_planes_wide<FMT, C, KEEP><<<grid, block, 0, st>>>(s, dst, n_blocks, plane_floats); return true
     HR_SPLIT_CASE(1); HR_SPLIT_CASE(2); HR_SPLIT_CASE(3); HR_SPLIT_CASE(4); HR_SPLIT_CASE(5); HR_SPLIT_CASE(6); HR_SPLIT_CASE(7); HR_SPLIT_CASE(8);
 #undef HR_SPLIT_CASE
     default: return false;
@@ -220,8 +254,9 @@ static bool launch_split_wide(const uint8_t *s, float *dst, uint64_t n_blocks, u
 }
 
 void launch_split_planes(int fmt, const void *src, float *dst, uint64_t frames, uint32_t channels, uint64_t plane_floats,
-                         hipStream_t st)
+                         bool keep_format, hipStream_t st)
 {
+    if (fmt == 0) keep_format = false;
     if (!frames) return;
     const uint8_t *s = static_cast<const uint8_t *>(src);
     // whole blocks of 1024 frames on the wide kernel (16-byte aligned source and planes), the rest on the generic one
@@ -230,20 +265,25 @@ void launch_split_planes(int fmt, const void *src, float *dst, uint64_t frames, 
         frames >= 1024) {
         const uint64_t nb = frames / 1024;
         const bool ok = fmt == 0 ? launch_split_wide<0>(s, dst, nb, channels, plane_floats, st)
-                      : fmt == 1 ? launch_split_wide<1>(s, dst, nb, channels, plane_floats, st)
-                                 : launch_split_wide<2>(s, dst, nb, channels, plane_floats, st);
+                      : fmt == 1 ? (keep_format ? launch_split_wide<1, true>(s, dst, nb, channels, plane_floats, st)
+                                                : launch_split_wide<1>(s, dst, nb, channels, plane_floats, st))
+                                 : (keep_format ? launch_split_wide<2, true>(s, dst, nb, channels, plane_floats, st)
+                                                : launch_split_wide<2>(s, dst, nb, channels, plane_floats, st));
         if (ok) done = nb * 1024;
     }
     if (done == frames) return;
     const uint32_t B = fmt == 0 ? 4 : fmt == 1 ? 2 : 3;
     s += done * channels * B;
-    dst += done * 2;
+    // (the generic kernel addresses plane p at dst + p * plane_floats plus its own frame offset)
+    dst = keep_format ? reinterpret_cast<float *>(reinterpret_cast<uint8_t *>(dst) + done * 2 * B) : dst + done * 2;
     frames -= done;
     uint64_t blocks = (frames + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
     const dim3 grid(static_cast<uint32_t>(blocks)), block(256);
     if (fmt == 0) k_split_planes<0><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
+    else if (fmt == 1 && keep_format) k_split_planes<1, true><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
     else if (fmt == 1) k_split_planes<1><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
+    else if (keep_format) k_split_planes<2, true><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
     else k_split_planes<2><<<grid, block, 0, st>>>(s, dst, frames, channels, plane_floats);
 }
 

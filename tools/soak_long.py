@@ -71,16 +71,19 @@ def main():
             if first:
                 for (pcm, fs, tag), g in zip(cases, first):
                     ref = oracle_lib.loudnorm_measure(pcm[: fs * 6], fs)
-                    check(g, ref, (seed, "loudnorm first pass", tag))
+                    # libebur128's 0.1 LU histogram makes the result a step function of the block energies, and the
+                    # oracle's 4th-order direct form II differs from the GPU's two biquads by ~1e-8 at 192 kHz: a block
+                    # that sits on a bin boundary moves the mean by 0.1 LU / blocks (seed 133: 1.7e-3 LU, 57 blocks)
+                    check(g, ref, (seed, "loudnorm first pass", tag), tol=0.11 / max(1, ref["n_blocks"]) + 1e-6)
             print(f"seed {seed} gate_mode {gate} tp_mode {tp}: {len(cases)} tracks ok, {time.time() - t0:.0f} s", flush=True)
 
 
-def check(g, ref, tag):
+def check(g, ref, tag, tol=1e-6):
     ok = g["status"] == 0 and g["n_blocks"] == ref["n_blocks"]
     if "n_gated" in ref:
         ok = ok and g["n_gated"] == ref["n_gated"]
     if math.isfinite(ref["integrated_lufs"]):
-        ok = ok and abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+        ok = ok and abs(g["integrated_lufs"] - ref["integrated_lufs"]) < tol
     else:
         ok = ok and g["integrated_lufs"] == ref["integrated_lufs"]
     ok = ok and g["peak_per_ch"] == ref["peak_per_ch"]
