@@ -302,6 +302,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     // (the host pads every rate's item list to a multiple of 4 with n_rows == 0 items: the four waves of a
     // workgroup share tables and a barrier per step, so all of them run all steps)
     const FusedItem it = items[item_idx];
+#if defined(HR_EXP_PRIO) && HR_EXP_PRIO == 1
+    if (blockIdx.x & 1) __builtin_amdgcn_s_setprio(1);
+#endif
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
     const bool passthru0 = r.tp_passthru0 != 0;  // else (BS.1770 bank) the sample peak bounds nothing and phase 0 is screened
@@ -501,10 +504,22 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         constexpr bool SHORT = decltype(short_c)::value;
         constexpr int KK = decltype(slot_c)::value;  // k mod 3
         // ---- piece k has landed?  (everything this wave has in flight: the DMA and the A fragments)
+#ifdef HR_EXP_NO_VMWAIT
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#endif
         // every wave's share of the shared tables has landed, and nobody still reads the halves that this
         // step's DMA is about to overwrite
+#ifndef HR_EXP_NO_BARRIER
         __builtin_amdgcn_s_barrier();
+#endif
+#if defined(HR_EXP_PRIO) && HR_EXP_PRIO == 2
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#if defined(HR_EXP_PRIO) && HR_EXP_PRIO == 3
+        __builtin_amdgcn_s_setprio(3);
+#endif
         if constexpr (INF == 2) {
             unsigned w[25];
             const char *rot = my_lds + rd_swz * 16;  // source chunk q sits at position (q + rd_swz) mod 6
@@ -746,6 +761,12 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             }
         };
         const bool fused_step = DO_KW && k < T_full;
+#if defined(HR_EXP_PRIO) && HR_EXP_PRIO == 2
+        __builtin_amdgcn_s_setprio(3);
+#endif
+#if defined(HR_EXP_PRIO) && HR_EXP_PRIO == 3
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (fused_step) {
             fused_block();
         } else {
@@ -1327,6 +1348,10 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
 #define HR_FUSED_CASE(MT, SMALL)                                                                                      \
     k_fused_f32s<DO_KW, DO_TP, MT, SMALL, INF><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, \
                                                                           fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg)
+#ifdef HR_FAST_BUILD
+    if constexpr (DO_KW && DO_TP && INF == 0) { HR_FUSED_CASE(3, true); }
+    (void)tp_class;
+#else
     if constexpr (!DO_TP) {
         HR_FUSED_CASE(1, false);
     } else {
@@ -1339,6 +1364,7 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
         default: HR_FUSED_CASE(3, true); break;
         }
     }
+#endif
 #undef HR_FUSED_CASE
 }
 
@@ -1378,8 +1404,16 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
     const dim3 grid((n_items + 3) / 4), block(256);
     // (the data-movement-only ablation build takes just its piece buffers: more workgroups per CU, which shows how
     // the stream rate depends on the bytes in flight)
-    const size_t lds = variant == 3 ? 4 * kPieceLds : kGroupLds;
+    size_t lds = variant == 3 ? 4 * kPieceLds : kGroupLds;
+#ifdef HR_EXPERIMENTS
+    static const int lds_pad = std::getenv("HR_EXP_LDS_PAD") ? std::atoi(std::getenv("HR_EXP_LDS_PAD")) : 0;  // occupancy experiments
+    lds += lds_pad;
+    if (lds > 65536)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_f32s<true, true, 3, true, 0>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
+#endif
     uint2 *cands = static_cast<uint2 *>(fs.cands);
+#ifndef HR_FAST_BUILD
     if (variant == 4) {  // full pass, K-weighting and true peak in separate waves
         switch (tp_class) {
         case 0: launch_split_case<1, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
@@ -1392,6 +1426,7 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
         k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
         return;
     }
+#endif
     if (variant == 5 || variant == 6) {  // full pass on stereo s16 / s24
         if (variant == 5) launch_class<true, true, 1>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
         else launch_class<true, true, 2>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
