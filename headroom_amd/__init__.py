@@ -19,7 +19,8 @@ FMT_F32, FMT_S16, FMT_S24, FMT_S32, FMT_F64 = range(5)
 GATE_EBUR128, GATE_EXACT, GATE_LOUDNORM = range(3)
 TP_SWR192K, TP_BS1770, TP_SAMPLE = range(3)
 TRACK_DEVICE_PCM = 1
-OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RATE, ERR_FORMAT, ERR_TOO_LARGE = 0, -1, -2, -3, -4, -5, -6, -7
+OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RATE, ERR_FORMAT, ERR_TOO_LARGE, ERR_NOT_READY = 0, -1, -2, -3, -4, -5, -6, -7, -8
+NOALLOC_MAX_HOP_CHANNELS = 65536
 GAIN_FFMPEG_LOSSLESS, GAIN_MP3_LOSSLESS, GAIN_MP3_REENCODE, GAIN_AAC_LOSSLESS, GAIN_AAC_REENCODE, GAIN_NONE = range(6)
 KIND_LOSSLESS, KIND_MP3, KIND_AAC = range(3)
 _FMT_BYTES = {FMT_F32: 4, FMT_S16: 2, FMT_S24: 3, FMT_S32: 4, FMT_F64: 8}
@@ -76,7 +77,8 @@ class HrPcmInfo(C.Structure):
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
-           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass", "hr_pcm_gain_file"]
+           "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass", "hr_pcm_gain_file",
+           "hr_analyze_device_noalloc"]
 
 _lib = None
 
@@ -106,6 +108,7 @@ def lib():
     L.hr_free_pinned.argtypes = [C.c_void_p]
     L.hr_free_pinned.restype = None
     L.hr_analyze_batch.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.c_size_t, C.POINTER(HrResult)]
+    L.hr_analyze_device_noalloc.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(HrResult)]
     L.hr_block_energies.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double), C.c_uint64,
                                     C.POINTER(C.c_double), C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     L.hr_shard_head.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double)]
@@ -259,6 +262,13 @@ class Meter:
         """hr_analyze_batch on a TrackBatch: the descriptor and result arrays are the caller's and live across calls, as
         they would in a C or Rust caller; nothing is converted.  batch.results() turns the last results into dicts."""
         _check(lib().hr_analyze_batch(self._h, batch.tracks, batch.n, batch.out), "hr_analyze_batch")
+
+    def analyze_device_noalloc(self, spec):
+        """hr_analyze_device_noalloc: one device-resident track, workspace from the library's static device array.
+        Returns (rc, result dict): the caller looks at rc (size / readiness errors are part of the contract)."""
+        r = HrResult()
+        rc = lib().hr_analyze_device_noalloc(self._h, C.byref(spec.c), C.byref(r))
+        return rc, _result_dict(r, spec.channels or 0)
 
     def loudnorm_first_pass(self, specs):
         """hr_loudnorm_first_pass: what `ffmpeg -af loudnorm=print_format=json` measures (src/analyzer.rs:253-267)."""

@@ -24,13 +24,29 @@ using namespace hr;
 
 namespace {
 
+// A fixed piece of device memory that workspace buffers are carved from instead of hipMalloc
+// (hr_analyze_device_noalloc: the library's static scratch array).
+struct Arena {
+    char *base = nullptr;
+    size_t cap = 0, used = 0;
+};
+
 struct DevBuf {
     void *p = nullptr;
     size_t cap = 0;
+    Arena *arena = nullptr;  // non-null: carve from the arena, never allocate or free
     // grow-only; returns false on allocation failure
     bool ensure(size_t bytes)
     {
         if (bytes <= cap) return true;
+        if (arena) {
+            const size_t off = (arena->used + 255) / 256 * 256;
+            if (off > arena->cap || bytes > arena->cap - off) return false;  // (the old piece, if any, is simply left behind)
+            p = arena->base + off;
+            cap = bytes;
+            arena->used = off + bytes;
+            return true;
+        }
         if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
         size_t want = bytes + bytes / 4 + 4096;
         if (hipMalloc(&p, want) != hipSuccess) {
@@ -41,7 +57,7 @@ struct DevBuf {
         cap = want;
         return true;
     }
-    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+    void release() { if (p && !arena) (void)hipFree(p); p = nullptr; cap = 0; }
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
@@ -102,7 +118,25 @@ struct hr_ctx {
     // state of an open time shard (hr_shard_pass1 .. hr_shard_pass2)
     bool shard_open = false;
     Group *shard_group = nullptr;
+
+    bool no_alloc = false;  // inside hr_analyze_device_noalloc: workspace comes from the static scratch array, nothing is widened
+    // every grow-only workspace buffer (not the device tables)
+    std::vector<DevBuf *> workspace()
+    {
+        return {&widened, &resampled, &parents_d, &counters, &gate_items, &gate_parts, &st_hist, &tracks_d, &items_d, &fitems_d,
+                &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos};
+    }
 };
+
+// ---- workspace of hr_analyze_device_noalloc: one array per GPU that the library runs on, held until the process ends ----
+// Host code never uses the array's name as an address: hr_init asks the runtime for the array's address on the current
+// device (hipGetSymbolAddress) and keeps it per device; kernels, memsets and copies take that pointer.
+constexpr size_t kScratchBytes = 8u << 20;
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+constexpr int kMaxDevices = 64;
+static void *g_scratch_ptr[kMaxDevices];      // per device; filled once by hr_init under g_scratch_init_mu
+static std::mutex g_scratch_init_mu;
+static std::mutex g_scratch_mu[kMaxDevices];  // calls on one GPU share that GPU's array: they are serialised here
 
 #define HIPCHK(expr)                                                                      \
     do {                                                                                  \
@@ -588,6 +622,7 @@ bool fused_s16(const hr_ctx *ctx, const hr_track &t, const void *dev)
 bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = nullptr)
 {
     const uint32_t hop = t.sample_rate / 10;
+    if (ctx->no_alloc) return false;  // the planes would need a PCM-sized buffer: such tracks take the generic kernels there
     if (ctx->cfg.engine == 1 || hop < 64 || t.frames / hop < 2 || hop * 8ull * 64 >= 0xffffffffull) return false;
     if (t.fmt != HR_FMT_F32 && t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) return false;
     if (t.fmt == HR_FMT_F32 && t.channels == 2) return false;  // the fused kernel reads it as it is
@@ -716,6 +751,15 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     if (n <= 0) return HR_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;
     HIPCHK(hipSetDevice(c.device));
+    if (c.device < kMaxDevices) {
+        // address of this device's copy of the scratch array (each GPU holds its own, at its own address)
+        std::lock_guard<std::mutex> lk(g_scratch_init_mu);
+        if (!g_scratch_ptr[c.device]) {
+            void *sp = nullptr;
+            HIPCHK(hipGetSymbolAddress(&sp, HIP_SYMBOL(scratch)));
+            g_scratch_ptr[c.device] = sp;
+        }
+    }
     hr_ctx *ctx = new hr_ctx();
     ctx->cfg = c;
     if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
@@ -813,6 +857,57 @@ int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *o
     }
     flush();
     return fatal;
+}
+
+int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out)
+{
+    if (!ctx || !track || !out) return HR_ERR_INVALID;
+    if (!(track->flags & HR_TRACK_DEVICE_PCM)) return HR_ERR_INVALID;  // a host buffer would need a staging allocation
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const int v = validate_track(ctx, *track);
+    if (v) return v;
+    const uint32_t hop = track->sample_rate / 10;
+    const uint64_t hops = track->frames / hop;
+    if (hops * track->channels > HR_NOALLOC_MAX_HOP_CHANNELS) {
+        std::fprintf(stderr, "headroom_hip: hr_analyze_device_noalloc: %llu hops x %u channels exceed the limit of %u (the %zu-byte "
+                             "static workspace); use hr_analyze_batch\n",
+                     static_cast<unsigned long long>(hops), static_cast<unsigned>(track->channels),
+                     static_cast<unsigned>(HR_NOALLOC_MAX_HOP_CHANNELS), kScratchBytes);
+        return HR_ERR_TOO_LARGE;
+    }
+    // the rate's device tables are allocated when a rate is first seen: that must have happened in an earlier, ordinary call
+    bool resident = false;
+    for (uint32_t fs : ctx->rate_fs) resident |= fs == track->sample_rate;
+    if (!resident) return HR_ERR_NOT_READY;
+    const int dev = ctx->cfg.device;
+    if (dev >= kMaxDevices || !g_scratch_ptr[dev]) return HR_ERR_HIP;
+    HIPCHK(hipSetDevice(dev));
+    std::lock_guard<std::mutex> lk_dev(g_scratch_mu[dev]);
+    Arena arena;
+    arena.base = static_cast<char *>(g_scratch_ptr[dev]);
+    arena.cap = kScratchBytes;
+    // the context's own workspace steps aside for the call; every buffer is carved from the array instead
+    const std::vector<DevBuf *> ws = ctx->workspace();
+    std::vector<DevBuf> saved;
+    saved.reserve(ws.size());
+    for (DevBuf *b : ws) {
+        saved.push_back(*b);
+        *b = DevBuf{};
+        b->arena = &arena;
+    }
+    ctx->no_alloc = true;
+    ctx->shard_open = false;  // an open time shard's workspace is not the one pass 2 would find
+    ctx->last_total_ms = ctx->last_main_ms = 0;
+    std::memset(out, 0, sizeof *out);
+    out->integrated_lufs = out->true_peak_dbtp = out->rel_threshold_lufs = -std::numeric_limits<double>::infinity();
+    out->loudness_range_lu = out->lra_low_lufs = out->lra_high_lufs = out->lra_threshold_lufs = out->max_momentary_lufs =
+        out->max_shortterm_lufs = std::numeric_limits<double>::quiet_NaN();
+    int rc = analyze_group(ctx, track, std::vector<size_t>{0}, out);
+    ctx->no_alloc = false;
+    for (size_t i = 0; i < ws.size(); i++) *ws[i] = saved[i];
+    if (rc == HR_ERR_OOM) rc = HR_ERR_TOO_LARGE;  // the array was too small after all (the limit above is meant to exclude this)
+    if (rc) out->status = rc;
+    return rc;
 }
 
 int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint64_t cap_hops, double *block_powers,
@@ -1351,6 +1446,7 @@ const char *hr_strerror(int code)
     case HR_ERR_RATE: return "sample rate not supported by the selected true-peak mode";
     case HR_ERR_FORMAT: return "unsupported sample format or channel count";
     case HR_ERR_TOO_LARGE: return "input exceeds the entry point's limit";
+    case HR_ERR_NOT_READY: return "device tables for this sample rate are not resident yet (make one ordinary call at this rate first)";
     default: return "unknown error";
     }
 }

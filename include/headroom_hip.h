@@ -30,7 +30,8 @@ enum {
     HR_ERR_OOM = -4,           /* device or pinned allocation failed                         */
     HR_ERR_RATE = -5,          /* sample rate not supported by the selected true-peak mode   */
     HR_ERR_FORMAT = -6,        /* unknown sample format / channel count                      */
-    HR_ERR_TOO_LARGE = -7      /* input exceeds a stated limit of the entry point            */
+    HR_ERR_TOO_LARGE = -7,     /* input exceeds a stated limit of the entry point            */
+    HR_ERR_NOT_READY = -8      /* hr_analyze_device_noalloc: the rate's device tables are not resident yet */
 };
 
 /* interleaved PCM sample formats (what ffmpeg would decode `-map 0:a:0` to) */
@@ -120,6 +121,21 @@ void hr_free_pinned(void *p);
  * (src/cli.rs:403-435): results are in input order, a bad track sets out[i].status and does not
  * fail the batch (src/cli.rs:419-430).  Thread-safe per context (serialised internally). */
 int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out);
+
+/* hr_analyze_batch for ONE track that is already in HBM, without any allocation.  No counterpart in the reference: it is
+ * for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  The entry point calls no hipMalloc / hipFree and no allocating library routine: all device workspace
+ * (zero-state records, hop sums, block powers, histograms, candidate lists, work items) is carved from ONE static
+ * device array of 8 MiB inside the library, which every GPU the library runs on holds until the process ends.
+ * Requirements: track->flags has HR_TRACK_DEVICE_PCM (else HR_ERR_INVALID); hops x channels, hops = frames /
+ * (sample_rate / 10), at most HR_NOALLOC_MAX_HOP_CHANNELS (else HR_ERR_TOO_LARGE; stereo: 54 minutes); the context
+ * has already seen this sample rate in an ordinary call, which is when the rate's tables are allocated (else
+ * HR_ERR_NOT_READY).  Tracks that hr_analyze_batch would first split into stereo planes (mono, 5.1, 7.1) take the
+ * generic kernels here: same results, slower.  Calls on one GPU share that GPU's array (it keeps the last call's
+ * contents; everything that must start at zero is cleared per call) and are serialised by a per-GPU lock inside the
+ * library; results are those of hr_analyze_batch. */
+#define HR_NOALLOC_MAX_HOP_CHANNELS 65536u
+int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out);
 
 /* Debug / parity entry: per-hop K-weighted energies H[hop*channels + ch] and 400 ms block powers
  * (f_ebur128.c power_400, 1e-12 floor included) of one track.  Either output may be NULL.
