@@ -69,7 +69,8 @@ int main(int argc, char **argv)
         const std::string name = p.substr(p.find_last_of('/') == std::string::npos ? 0 : p.find_last_of('/') + 1);
         hr_analysis a;
         if (res[i].status) { std::fprintf(stderr, "warning: %s: %s\n", p.c_str(), hr_strerror(res[i].status)); continue; }
-        if (hr_gain_decision(res[i].integrated_lufs, res[i].true_peak_dbtp, HR_KIND_LOSSLESS, 0, 0, &mode, &a)) {
+        // the decision sees the measurement as the reference does: through loudnorm's "%.2f" text (src/analyzer.rs:273-280)
+        if (hr_gain_decision_for_result(&res[i], HR_KIND_LOSSLESS, 0, 0, &mode, &a)) {
             // src/analyzer.rs:284-290
             std::fprintf(stderr, "warning: %s: Non-finite loudness measurement (silent or unreadable audio)\n", p.c_str());
             continue;

@@ -78,7 +78,7 @@ EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_fr
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
            "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass", "hr_pcm_gain_file",
-           "hr_analyze_device_noalloc"]
+           "hr_analyze_device_noalloc", "hr_loudnorm_text_values", "hr_gain_decision_for_result"]
 
 _lib = None
 
@@ -130,6 +130,9 @@ def lib():
     L.hr_strerror.restype = C.c_char_p
     L.hr_gain_decision.argtypes = [C.c_double, C.c_double, C.c_int, C.c_int, C.c_uint32, C.POINTER(HrTpTarget),
                                    C.POINTER(HrAnalysis)]
+    L.hr_loudnorm_text_values.argtypes = [C.POINTER(HrResult), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.hr_gain_decision_for_result.argtypes = [C.POINTER(HrResult), C.c_int, C.c_int, C.c_uint32, C.POINTER(HrTpTarget),
+                                              C.POINTER(HrAnalysis)]
     _lib = L
     return L
 
@@ -415,4 +418,28 @@ def gain_decision(input_i, input_tp, kind=KIND_LOSSLESS, bitrate_kbps=None, spli
     out = HrAnalysis()
     rc = lib().hr_gain_decision(input_i, input_tp, kind, int(bitrate_kbps is not None), int(bitrate_kbps or 0),
                                 C.byref(mode) if mode else None, C.byref(out))
+    return rc, {f: getattr(out, f) for f, _ in HrAnalysis._fields_}
+
+
+def _as_result(lufs, dbtp, status=OK):
+    r = HrResult()
+    r.integrated_lufs, r.true_peak_dbtp, r.status = lufs, dbtp, status
+    return r
+
+
+def loudnorm_text_values(lufs, dbtp):
+    """hr_loudnorm_text_values: the two numbers after loudnorm's "%.2f" printing and the analyzer's parse."""
+    a, b = C.c_double(), C.c_double()
+    r = _as_result(lufs, dbtp)
+    _check(lib().hr_loudnorm_text_values(C.byref(r), C.byref(a), C.byref(b)), "hr_loudnorm_text_values")
+    return a.value, b.value
+
+
+def gain_decision_for_result(lufs, dbtp, kind=KIND_LOSSLESS, bitrate_kbps=None, split=None, status=OK):
+    """hr_gain_decision_for_result on a measurement (src/analyzer.rs:273-326: text rounding, then the decision)."""
+    mode = HrTpTarget(1, split[0], split[1]) if split else None
+    out = HrAnalysis()
+    r = _as_result(lufs, dbtp, status)
+    rc = lib().hr_gain_decision_for_result(C.byref(r), kind, int(bitrate_kbps is not None), int(bitrate_kbps or 0),
+                                           C.byref(mode) if mode else None, C.byref(out))
     return rc, {f: getattr(out, f) for f, _ in HrAnalysis._fields_}

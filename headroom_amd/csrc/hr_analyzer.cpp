@@ -5,6 +5,7 @@
 // Cargo.lock:961-964; README.md:282 states the value: 1.5 dB, fixed by the MP3/AAC global_gain step).
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -68,6 +69,42 @@ extern "C" int hr_gain_decision(double input_i, double input_tp, int kind, int h
     }
     out->status = HR_OK;
     return HR_OK;
+}
+
+// What the reference actually holds after src/analyzer.rs:273-280: af_loudnorm prints `input_i` / `input_tp` with
+// "%.2f" (the fixture at src/analyzer.rs:370-371 shows the format) and the analyzer parses that text with
+// str::parse::<f64>, so every later step -- the finite check, headroom, the 0.05 dB and 1.5 dB thresholds, the
+// one-decimal CSV fields -- sees the measurement rounded to two decimals.  printf rounds the exact binary value to
+// nearest (ties to even on the decimal expansion) and strtod, like Rust's parser, returns the double nearest to the
+// text; "-inf" / "inf" / "nan" survive the round trip as such.
+static double through_text_2dp(double v)
+{
+    char buf[64];
+    std::snprintf(buf, sizeof buf, "%.2f", v);
+    return std::strtod(buf, nullptr);
+}
+
+extern "C" int hr_loudnorm_text_values(const hr_result *r, double *input_i, double *input_tp)
+{
+    if (!r) return HR_ERR_INVALID;
+    if (input_i) *input_i = through_text_2dp(r->integrated_lufs);
+    if (input_tp) *input_tp = through_text_2dp(r->true_peak_dbtp);
+    return HR_OK;
+}
+
+extern "C" int hr_gain_decision_for_result(const hr_result *r, int kind, int has_bitrate, uint32_t bitrate_kbps,
+                                           const hr_tp_target *mode, hr_analysis *out)
+{
+    if (!r || !out) return HR_ERR_INVALID;
+    if (r->status != HR_OK) {  // the track failed to measure: the Err arm of analyze_file_with_target
+        *out = hr_analysis{};
+        out->gain_method = HR_GAIN_NONE;
+        out->status = r->status;
+        return r->status;
+    }
+    double i = 0, tp = 0;
+    hr_loudnorm_text_values(r, &i, &tp);
+    return hr_gain_decision(i, tp, kind, has_bitrate, bitrate_kbps, mode, out);
 }
 
 // ---- report rows: src/report.rs:29-59 (CSV header and record), labels src/analyzer.rs:80-100 ---------------------

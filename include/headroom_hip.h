@@ -258,9 +258,22 @@ typedef struct hr_analysis { /* AudioAnalysis minus the path strings, src/analyz
     int32_t status; /* HR_OK, or HR_ERR_INVALID for a non-finite measurement (analyzer.rs:284) */
 } hr_analysis;
 
-/* src/analyzer.rs:284-326 applied to one measurement. */
+/* src/analyzer.rs:284-326 applied to one measurement, on exactly the two numbers it is given. */
 int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
                      const hr_tp_target *mode, hr_analysis *out);
+
+/* The two numbers as the reference holds them after src/analyzer.rs:273-280: loudnorm prints `input_i` / `input_tp`
+ * with "%.2f" (src/analyzer.rs:102-106 receives them as strings) and the analyzer parses that text, so its headroom,
+ * its MIN_EFFECTIVE_GAIN (0.05 dB, :307) and GAIN_STEP (1.5 dB, :313) comparisons and its report all see the
+ * measurement rounded to two decimals.  A drop-in caller must feed the decision THESE values, not the full-precision
+ * fields of hr_result: tp = -0.5451 dBTP reads "-0.55" there (headroom 0.05: processed) but 0.0451 unrounded (skipped).
+ * "-inf" (silence) stays -inf and is then rejected by the finite check.  Either output may be NULL. */
+int hr_loudnorm_text_values(const hr_result *r, double *input_i, double *input_tp);
+
+/* hr_loudnorm_text_values followed by hr_gain_decision: the whole of src/analyzer.rs:273-326 for one measured track.
+ * A track whose measurement failed (r->status != HR_OK) yields that status (the Err arm, src/cli.rs:419-430). */
+int hr_gain_decision_for_result(const hr_result *r, int kind, int has_bitrate, uint32_t bitrate_kbps,
+                                const hr_tp_target *mode, hr_analysis *out);
 
 /* The measurement the reference literally asks FFmpeg for: the first pass of `-af loudnorm=print_format=json`
  * (src/analyzer.rs:253-267; `input_i`, `input_tp`, `input_lra`, `input_thresh` of its JSON).  af_loudnorm negotiates

@@ -97,6 +97,77 @@ def test_non_finite_measurement_is_rejected():
         assert rc == hr.ERR_INVALID and a["status"] == hr.ERR_INVALID
 
 
+# ---- the measurement as the reference sees it: loudnorm's "%.2f" text, parsed (src/analyzer.rs:102-106, 273-280) ----
+
+def ref_decision(input_i_text, input_tp_text, kind=None, kbps=None, target=-0.5):
+    """src/analyzer.rs:273-326 restated on the printed strings (Uniform target): what the reference would decide."""
+    i, tp = float(input_i_text), float(input_tp_text)
+    if not (math.isfinite(i) and math.isfinite(tp)):
+        return None
+    headroom = target - tp
+    lossy = kind in (hr.KIND_MP3, hr.KIND_AAC)
+    if headroom < 0.05:
+        return (hr.GAIN_NONE, 0.0, 0)
+    if not lossy:
+        return (hr.GAIN_FFMPEG_LOSSLESS, headroom, 0)
+    steps = math.floor(headroom / 1.5)
+    if steps >= 1:
+        return (hr.GAIN_AAC_LOSSLESS if kind == hr.KIND_AAC else hr.GAIN_MP3_LOSSLESS, steps * 1.5, steps)
+    return (hr.GAIN_AAC_REENCODE if kind == hr.KIND_AAC else hr.GAIN_MP3_REENCODE, headroom, 0)
+
+
+def test_text_values_round_like_printf_and_parse():
+    for v in (-0.5451, -0.5449, -0.545, -0.555, -2.004, -1.996, -14.004999, -23.0, 0.004999, 0.005, 2.675, -70.0, 1e-9, -1e-9):
+        i, tp = hr.loudnorm_text_values(v, v)
+        assert i == tp == float("%.2f" % v), v
+    i, tp = hr.loudnorm_text_values(-math.inf, -math.inf)
+    assert i == -math.inf and tp == -math.inf
+    i, tp = hr.loudnorm_text_values(math.nan, math.inf)
+    assert math.isnan(i) and tp == math.inf
+
+
+def test_decision_on_thresholds_follows_the_rounded_values():
+    # values straddling MIN_EFFECTIVE_GAIN (0.05 dB, src/analyzer.rs:307) and multiples of GAIN_STEP (1.5 dB, :313):
+    # the reference decides on the two-decimal text, the unrounded value would decide differently
+    cases = [(-0.5451, hr.KIND_LOSSLESS, None), (-0.5449, hr.KIND_LOSSLESS, None), (-0.546, hr.KIND_LOSSLESS, None),
+             (-0.554, hr.KIND_LOSSLESS, None), (-0.5549, hr.KIND_MP3, 320), (-2.004, hr.KIND_MP3, 320),
+             (-1.996, hr.KIND_MP3, 320), (-1.9951, hr.KIND_MP3, 320), (-2.0049, hr.KIND_AAC, 256), (-3.504, hr.KIND_AAC, 256),
+             (-3.496, hr.KIND_AAC, 256), (-3.4949, hr.KIND_MP3, 128), (-5.0, hr.KIND_MP3, 320), (-0.5, hr.KIND_LOSSLESS, None)]
+    flips = 0
+    for tp, kind, kbps in cases:
+        want = ref_decision("%.2f" % -14.237, "%.2f" % tp, kind, kbps)
+        rc, a = hr.gain_decision_for_result(-14.237, tp, kind=kind, bitrate_kbps=kbps)
+        assert rc == 0
+        assert a["input_tp"] == float("%.2f" % tp) and a["input_i"] == -14.24
+        assert (a["gain_method"], a["lossless_gain_steps"]) == (want[0], want[2]), (tp, a, want)
+        assert abs(a["effective_gain"] - want[1]) < 1e-12 and abs(a["headroom"] - (-0.5 - float("%.2f" % tp))) < 1e-12
+        rc, raw = hr.gain_decision(-14.237, tp, kind=kind, bitrate_kbps=kbps)
+        flips += (raw["gain_method"], raw["lossless_gain_steps"]) != (a["gain_method"], a["lossless_gain_steps"])
+    assert flips >= 4  # the cases really sit on the thresholds: the unrounded decision differs on several of them
+    # the one from the review: -0.5451 dBTP prints as "-0.55" -> headroom 0.05 -> processed; unrounded 0.0451 -> skipped
+    rc, a = hr.gain_decision_for_result(-10.0, -0.5451)
+    assert a["gain_method"] == hr.GAIN_FFMPEG_LOSSLESS and abs(a["effective_gain"] - 0.05) < 1e-12
+    rc, a = hr.gain_decision(-10.0, -0.5451)
+    assert a["gain_method"] == hr.GAIN_NONE
+
+
+def test_decision_for_result_rejects_silence_and_failed_tracks():
+    rc, a = hr.gain_decision_for_result(-math.inf, -math.inf)  # loudnorm prints "-inf": src/analyzer.rs:282-290
+    assert rc == hr.ERR_INVALID and a["status"] == hr.ERR_INVALID and a["gain_method"] == hr.GAIN_NONE
+    rc, a = hr.gain_decision_for_result(-14.0, -3.0, status=hr.ERR_RATE)
+    assert rc == hr.ERR_RATE and a["status"] == hr.ERR_RATE
+
+
+def test_csv_row_double_rounds_like_the_reference():
+    # report.rs:53-58 prints {:.1} of the already two-decimal value: -0.549 -> "-0.55" -> "-0.6" there (ties: the binary
+    # value of -0.55 is just below the tie), whereas one rounding of -0.549 gives "-0.5"
+    rc, a = hr.gain_decision_for_result(-14.0, -0.549)
+    text = hr.report_csv([("a.wav", a)]).splitlines()[1].split(",")
+    assert text[4] == "%.1f" % float("%.2f" % -0.549)
+    rc, raw = hr.gain_decision(-14.0, -0.549)
+    assert hr.report_csv([("a.wav", raw)]).splitlines()[1].split(",")[4] == "-0.5"
+
+
 # ---- the product's tables vs the oracle's (two independent builds of the same published formulas) --
 
 def _tables_exe():

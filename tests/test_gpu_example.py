@@ -18,7 +18,7 @@ EXE = os.path.join(ROOT, "examples", "headroom_scan")
 
 def expected_row(oracle, name, seen, fs, **kw):
     ref = oracle.measure(seen, fs, **kw)
-    rc, a = hr.gain_decision(ref["integrated_lufs"], ref["true_peak_dbtp"])
+    rc, a = hr.gain_decision_for_result(ref["integrated_lufs"], ref["true_peak_dbtp"])
     assert rc == 0
     return hr.report_csv([(name, a)]).splitlines()[1], a
 
