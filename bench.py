@@ -31,10 +31,21 @@ def cpu_baseline(n_tracks, threads):
     """The oracle (a scalar f64 restatement of FFmpeg's algorithm: "port") timed on the host cores on a
     bounded sample of the same workload: n_tracks full 3-minute tracks, one thread per track (mirrors one
     ffmpeg process per rayon worker, src/cli.rs:407)."""
+    import subprocess
     from concurrent.futures import ThreadPoolExecutor
 
     import oracle_lib
     oracle_lib.build()
+    # the timed leg uses a build of the same source for THIS machine's cores (-O3 -march=native, SURVEY.md 8d)
+    build = "-O2 -mfma (the portable build: gcc or make missing on this machine)"
+    try:
+        subprocess.check_call(["make", "-C", oracle_lib.ORACLE_DIR, "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        native = os.path.join(oracle_lib.ORACLE_DIR, "_native", "libhr_oracle_native.so")
+        if os.path.exists(native) and oracle_lib._lib is None:
+            oracle_lib.LIB_PATH = native
+            build = "-O3 -march=native"
+    except Exception:
+        pass
     frames = FS * SECONDS
     tracks = [oracle_lib.synth_track(1000 + i, FS, CH, frames) for i in range(n_tracks)]
     t0 = time.perf_counter()
@@ -43,6 +54,8 @@ def cpu_baseline(n_tracks, threads):
     dt = time.perf_counter() - t0
     hours = n_tracks * SECONDS / 3600.0
     return {"value": hours / dt, "unit": "audio-hours/s", "cores": threads, "kind": "port",
+            "host_cores_visible": os.cpu_count(), "cores_note": "cores = threads actually used, one per core of this job's CPU share "
+            "(16 per GPU on the box; os.cpu_count() shows the whole machine)", "build": build,
             "sample": f"{n_tracks} x {SECONDS} s 44.1 kHz stereo f32 tracks of the same synthetic generator, "
                       f"one thread per track, oracle mode ebur128 gating + 192 kHz interpolation, {dt:.2f} s wall"}, res, tracks
 
@@ -186,7 +199,13 @@ def main():
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
         if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2" and args.tp_mode == "swr192k":
-            threads = min(16, os.cpu_count() or 1)
+            # one thread per core of the job's CPU share: the scheduler's affinity mask when it is narrower than the
+            # machine, else the box's documented share of 16 cores per GPU
+            try:
+                share = len(os.sched_getaffinity(0))
+            except AttributeError:
+                share = os.cpu_count() or 1
+            threads = max(1, min(16, share))
             base, ref, cpu_tracks = cpu_baseline(threads, threads)
             line["cpu_baseline"] = base
             # the same tracks (seeds 1000..) are the first tracks of rank 0's batch: parity spot check

@@ -102,6 +102,7 @@ struct hr_ctx {
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<WorkItem> h_ovf_items, h_gate_items;
     bool no_s16_direct = false;  // HR_NO_S16_DIRECT=1: stereo s16 is widened into f32 planes first, as before
+    // the next three are set only by the experiments library (-DHR_EXPERIMENTS, make exp); always false / 0 in the shipped one
     bool serial_tail = false;  // HR_SERIAL_TAIL=1 (timing experiments): tail kernels before the fused kernel, not beside it
     bool split = false;  // HR_FUSED_SPLIT=1: k_fused_split (K-weighting and true peak in separate waves) instead of k_fused_f32s
     int ablate = 0;  // HR_ABLATE=1|2|3: timing-only builds of the fused kernel (results are then wrong)
@@ -763,9 +764,11 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     hr_ctx *ctx = new hr_ctx();
     ctx->cfg = c;
     if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
+#ifdef HR_EXPERIMENTS  // timing switches of the experiments library (make exp); the shipped library reads none of them
     if (const char *ab = std::getenv("HR_ABLATE")) ctx->ablate = std::atoi(ab);
     if (const char *sp = std::getenv("HR_FUSED_SPLIT")) ctx->split = std::atoi(sp) != 0;
     if (const char *se = std::getenv("HR_SERIAL_TAIL")) ctx->serial_tail = std::atoi(se) != 0;
+#endif
     if (const char *ns = std::getenv("HR_NO_S16_DIRECT")) ctx->no_s16_direct = std::atoi(ns) != 0;
     if (c.stream) ctx->stream = static_cast<hipStream_t>(c.stream);
     else {

@@ -37,6 +37,19 @@
 #include "hr_device.hpp"
 #include "hr_kernels.hpp"
 
+// Timing experiments (ablation bits of `dbg`, the HR_EXP_* switches, the split-wave kernel, environment switches of the
+// launchers) exist only in builds with -DHR_EXPERIMENTS (make exp -> libheadroom_hip_exp.so): several of them make the
+// results wrong on purpose, so the shipped library does not contain them.
+#ifdef HR_EXPERIMENTS
+#define HR_DBG(dbg, bit) (((dbg) & (bit)) != 0)
+#else
+#define HR_DBG(dbg, bit) false
+#if defined(HR_EXP_NO_FRAGS) || defined(HR_EXP_NO_MFMA) || defined(HR_EXP_NO_KW) || defined(HR_EXP_NO_REDUCE) || \
+    defined(HR_EXP_NO_AF) || defined(HR_EXP_NO_BARRIER) || defined(HR_EXP_NO_VMWAIT) || defined(HR_EXP_PRIO)
+#error "HR_EXP_* switches need -DHR_EXPERIMENTS"
+#endif
+#endif
+
 namespace hr {
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -293,8 +306,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 {
     // dbg bit 6 (64, a production switch of the K-weighting-only build): also track the sample peak of the frames read
     // (HR_TP_SAMPLE, and 192 kHz input whose "true peak" is the sample peak)
-    // other dbg bits (timing experiments only, results are wrong when set): 1 = never list candidates,
-    // 16 = no PCM / carry-table DMA after the first piece
+    // other dbg bits (HR_EXPERIMENTS builds only; results are wrong when set): 1 = never list candidates,
+    // 16 = no PCM / carry-table DMA after the first piece, 32 = every piece DMA re-reads piece 0
     extern __shared__ __attribute__((aligned(16))) char smem[];  // kGroupLds
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -580,8 +593,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             }
         }
         // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
-        if (k < T && !(dbg & 16)) {
-            const char *src = wave_base + ((dbg & 32) ? 0 : static_cast<size_t>(k + 1) * PB);  // dbg 32: re-read piece 0 (cache hits)
+        if (k < T && !HR_DBG(dbg, 16)) {
+            const char *src = wave_base + (HR_DBG(dbg, 32) ? 0 : static_cast<size_t>(k + 1) * PB);  // dbg 32 (experiments): re-read piece 0 (cache hits)
 #pragma unroll
             for (int j = 0; j < NDMA; j++) dma16(src, dma_off[j], lbuf + j * 1024);
             if constexpr (DO_KW) {
@@ -789,7 +802,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                     margin = fmaxf(margin, mm - thr_l[ch][nt]);
                 }
             const unsigned long long any = __ballot(margin >= 0.0f);
-            if (any != 0ull && !(dbg & 1)) {  // wave-uniform, rare
+            if (any != 0ull && !HR_DBG(dbg, 1)) {  // wave-uniform, rare
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
 #pragma unroll
@@ -885,6 +898,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     }
 }
 
+#ifdef HR_EXPERIMENTS
 // ---- k_fused_split: the same pass with the two halves of the work in SEPARATE waves -------------------------------
 // A workgroup is eight waves = four pairs; a pair owns one item (64 rows).  Wave p (0..3) of a pair K-weights
 // (f64 VALU only), wave p+4 screens the true peak (f16 MFMA + f32 VALU); both read the SAME 8 KiB LDS image of the
@@ -1298,6 +1312,8 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
     }
 }
 
+#endif  // HR_EXPERIMENTS (k_fused_split)
+
 // Exact evaluation of the candidates that can still be the maximum.  One workgroup per wave item of the
 // fused kernel, one thread per candidate slot.
 __global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__restrict__ tracks,
@@ -1370,6 +1386,7 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
 
 int fused_tp_class(int tp_mt, int tp_last_rows) { return (tp_mt - 1) * 2 + (tp_last_rows <= 8 ? 1 : 0); }
 
+#ifdef HR_EXPERIMENTS
 template <int MT, bool SMALL, int PAIRS, int RING>
 static void launch_split_geom(uint32_t n_items, hipStream_t st, const TrackDesc *tracks, const RateDev *rates,
                               const FusedItem *items, HopRec *recs, uint2 *cands, const FusedScratch &fs,
@@ -1396,6 +1413,8 @@ static void launch_split_case(dim3 grid, hipStream_t st, const TrackDesc *tracks
     else launch_split_geom<MT, SMALL, 4, 4>(n_items, st, tracks, rates, items, recs, cands, fs, peaks, wave_map);
 }
 
+#endif  // HR_EXPERIMENTS (split-wave launchers)
+
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
                        HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int tp_class, int dbg,
                        hipStream_t st)
@@ -1413,7 +1432,7 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 #endif
     uint2 *cands = static_cast<uint2 *>(fs.cands);
-#ifndef HR_FAST_BUILD
+#if defined(HR_EXPERIMENTS) && !defined(HR_FAST_BUILD)
     if (variant == 4) {  // full pass, K-weighting and true peak in separate waves
         switch (tp_class) {
         case 0: launch_split_case<1, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;

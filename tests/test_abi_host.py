@@ -49,6 +49,14 @@ def test_no_device_means_error_not_fallback():
     assert e.value.code == hr.ERR_NO_DEVICE
 
 
+def test_shipped_library_has_no_experiment_switches():
+    """Timing experiments (HR_ABLATE and friends make the results wrong on purpose) compile only into
+    libheadroom_hip_exp.so (-DHR_EXPERIMENTS); the shipped library must not even contain their names."""
+    data = open(hr.LIB_PATH, "rb").read()
+    for name in (b"HR_ABLATE", b"HR_FUSED_SPLIT", b"HR_SERIAL_TAIL", b"HR_WAVE_MAP", b"HR_SPLIT_GEOM", b"HR_EXP_", b"k_fused_split"):
+        assert name not in data, name
+
+
 def test_strerror():
     assert hr.lib().hr_strerror(0) == b"ok"
     assert b"no HIP device" in hr.lib().hr_strerror(hr.ERR_NO_DEVICE)

@@ -421,21 +421,6 @@ def test_integer_stereo_tracks_take_the_fused_kernel(oracle, meters, fs):
                    for g in got)
 
 
-@pytest.mark.parametrize("fs", [44100, 48000, 96000])
-def test_split_wave_kernel_is_bit_identical(oracle, meters, fs, monkeypatch):
-    """HR_FUSED_SPLIT=1 (k_fused_split: K-weighting and true peak in separate waves) gives the oracle's results too."""
-    monkeypatch.setenv("HR_FUSED_SPLIT", "1")
-    m = hr.Meter(device=0)
-    try:
-        pcm = signals.seeded_noise(31 + fs, fs * 9 + 321, 2, -12.0)
-        pcm[: fs] *= 0.003
-        got, ref = check_against_oracle(oracle, m, pcm, fs)
-        base = meters().analyze(pcm, fs)
-        assert got["integrated_lufs"] == base["integrated_lufs"] and got["peak_per_ch"] == base["peak_per_ch"]
-    finally:
-        m.close()
-
-
 # ---- loudness range, maximum momentary / short-term loudness (SURVEY.md 8f rank 3) ------------------------------
 
 def check_range(oracle, m, pcm, fs, gate, **kw):
