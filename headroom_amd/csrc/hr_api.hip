@@ -91,7 +91,7 @@ struct hr_ctx {
     std::vector<RateDev> rates_h;
     std::vector<void *> rate_allocs;
     std::vector<std::pair<uint32_t, const double *>> swr_banks;  // libswresample banks for hr_loudnorm_first_pass, per rate
-    DevBuf rates_d, ebu_energy, ln_energy, ln_bounds, unit_tap;
+    DevBuf rates_d, ebu_energy, ebu_edges, ln_energy, ln_bounds, unit_tap;
 
     // workspace (grow-only)
     DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
@@ -488,14 +488,14 @@ int run_gating(hr_ctx *ctx, Group &g, bool finalize, bool range_parts = false)
     const uint32_t ni = static_cast<uint32_t>(items.size());
     HIPCHK(hipMemsetAsync(ctx->hist.p, 0, hist_bytes, st));
     launch_block_hist(dt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
-                      ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), st);
+                      ctx->ebu_edges.as<double>(), ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), st);
     launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
-                      ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
+                      ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
                       ctx->gate_parts.as<GatePart>(), !finalize, ctx->outs.as<TrackOut>(), st);
     if (finalize || range_parts) {
         HIPCHK(hipMemsetAsync(ctx->st_hist.p, 0, hist_bytes, st));
         launch_range_stats(dt, nt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
-                           ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->st_hist.as<uint32_t>(),
+                           ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->st_hist.as<uint32_t>(),
                            ctx->gate_parts.as<GatePart>(), finalize, ctx->outs.as<TrackOut>(), st);
     }
     HIPCHK(hipGetLastError());
@@ -781,6 +781,7 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
     int rc = upload(ctx->ebu_energy, ebur128_bin_energy().data(), kEbuBins * sizeof(double), ctx->stream);
+    if (!rc) rc = upload(ctx->ebu_edges, ebur128_bin_edges().data(), 3 * kEbuBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_energy, loudnorm_bin_energy().data(), kLnBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_bounds, loudnorm_bin_bounds().data(), (kLnBins + 1) * sizeof(double), ctx->stream);
     double unit[kSwrTaps] = {0};
@@ -797,7 +798,7 @@ void hr_destroy(hr_ctx *ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
+    for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ebu_edges, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
                       &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
@@ -1189,11 +1190,11 @@ int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_r
     if (rc) return rc;
     if (!ctx->blk_powers.ensure(sizeof(double))) return HR_ERR_OOM;
     launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(),
-                      ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ln_energy.as<double>(),
+                      ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(),
                       ctx->ln_bounds.as<double>(), ctx->gate_parts.as<GatePart>(), false, ctx->outs.as<TrackOut>(), st);
     launch_range_stats(ctx->tracks_d.as<TrackDesc>(), 1, nullptr, 0, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(),
                        ctx->blk_powers.as<double>(), ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(),
-                       ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), true, ctx->outs.as<TrackOut>(), st);
+                       ctx->ebu_edges.as<double>(), ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), true, ctx->outs.as<TrackOut>(), st);
     HIPCHK(hipGetLastError());
     HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));

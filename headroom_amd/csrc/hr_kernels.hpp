@@ -15,20 +15,23 @@ void launch_hop_zero_state_list(int fmt, const TrackDesc *tracks, const RateDev 
                                 uint32_t n_items, HopRec *recs, hipStream_t st);
 void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
                         const HopRec *recs, double *hop_sums, hipStream_t st);
+// ebu_edges: hr_tables.hpp ebur128_bin_edges() on the device (3 x kEbuBins powers): f_ebur128.c's bin decisions without a
+// device logarithm.
 // Gating runs in chunks of kGateChunk blocks, one workgroup each (items: track, pad = chunk index, first = first block);
 // `hist` / `st_hist` ([n_tracks][kEbuBins]) must be zero before launch_block_hist / launch_range_stats.
 void launch_block_hist(const TrackDesc *tracks, const WorkItem *items, uint32_t n_items, int gate_mode, const double *hop_sums,
-                       const double *ln_bounds, double *block_powers, uint32_t *hist, GatePart *parts, hipStream_t st);
+                       const double *ln_bounds, const double *ebu_edges, double *block_powers, uint32_t *hist, GatePart *parts,
+                       hipStream_t st);
 // per track: sums the chunks' partial sums into `outs` (tracks with n_parts == 0 bring reduced sums in `outs` already);
 // unless reduce_only, also the relative gate and the gated mean
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
-                       const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
+                       const uint32_t *hist, const double *ebu_energy, const double *ebu_edges, const double *ln_energy,
                        const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st);
 // loudness range + maximum 400 ms / 3 s powers (after launch_block_hist: reads the block powers): the chunks' histograms
 // and partial sums, and with `finalize` the per-track result (n_items == 0: only that, from reduced partials)
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
                         const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
-                        uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st);
+                        const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st);
 // hop sums of the stereo planes of a split track -> the track's own (hop, channel) slots; one workgroup per parent
 void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
 // libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases/step) interleaved f64 frames

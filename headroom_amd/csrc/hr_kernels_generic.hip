@@ -243,9 +243,21 @@ __device__ __forceinline__ unsigned long long block_reduce_sum_u64(unsigned long
     return r;
 }
 
+// largest bin b with edges[b] <= p (the caller has checked p >= edges[0]): hr_tables.cpp ebur128_bin_edges
+__device__ __forceinline__ int ebu_bin_from_edges(const double *__restrict__ edges, double p)
+{
+    int lo = 0, hi = kEbuBins;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (p >= edges[mid]) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
 __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
                                                     int gate_mode, const double *__restrict__ hop_sums,
                                                     const double *__restrict__ ln_bounds,
+                                                    const double *__restrict__ ebu_edges,
                                                     double *__restrict__ block_powers,
                                                     uint32_t *__restrict__ hist, GatePart *__restrict__ parts)
 {
@@ -274,11 +286,9 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
         power /= bins;
         block_powers[t.blk_base + jj] = power;
         if (gate_mode == 0) {
-            const double loud = -0.691 + 10.0 * log10(power);
-            if (loud >= -70.0) {
-                int b = static_cast<int>((loud - (-70.0)) * 100);
-                b = b < 0 ? 0 : (b > kEbuBins - 1 ? kEbuBins - 1 : b);
-                atomicAdd(&hg[b], 1u);
+            // loud = -0.691 + 10 log10(power) >= -70 and its bin, decided on the power itself (ebur128_bin_edges)
+            if (power >= ebu_edges[0]) {
+                atomicAdd(&hg[ebu_bin_from_edges(ebu_edges, power)], 1u);
                 sum_kept += power;
                 n_kept++;
             }
@@ -314,6 +324,7 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
                                                     const double *__restrict__ block_powers,
                                                     const uint32_t *__restrict__ hist,
                                                     const double *__restrict__ ebu_energy,
+                                                    const double *__restrict__ ebu_edges,
                                                     const double *__restrict__ ln_energy,
                                                     const double *__restrict__ ln_bounds,
                                                     const GatePart *__restrict__ parts, int reduce_only,
@@ -346,9 +357,8 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
     if (gate_mode == 0) {
         double rt = o.sum_kept / static_cast<double>(n_kept);
         if (!rt) rt = 1e-12;
-        const double rel_thr = (-0.691 + 10.0 * log10(rt)) + (-10.0);
-        int gp = static_cast<int>((rel_thr - (-70.0)) * 100);
-        gp = gp < 0 ? 0 : (gp > kEbuBins - 1 ? kEbuBins - 1 : gp);
+        // first bin of the relative gate, (int)(((-0.691 + 10 log10(rt)) - 10 + 70) * 100) clipped: table 1 of the edges
+        const int gp = ebu_bin_from_edges(ebu_edges + kEbuBins, rt);
         double isum = 0;
         unsigned long long nint = 0;
         for (int i = gp + threadIdx.x; i < kEbuBins; i += blockDim.x) {
@@ -443,7 +453,8 @@ __device__ __forceinline__ double block_reduce_max(double v, double *sh)
 __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
                                                      int gate_mode, const double *__restrict__ hop_sums,
                                                      const double *__restrict__ block_powers,
-                                                     const double *__restrict__ ln_bounds, uint32_t *__restrict__ st_hist,
+                                                     const double *__restrict__ ln_bounds,
+                                                     const double *__restrict__ ebu_edges, uint32_t *__restrict__ st_hist,
                                                      GatePart *__restrict__ parts)
 {
     __shared__ uint32_t hh[kEbuBins];
@@ -476,11 +487,8 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
         power /= bins;
         max_s = power > max_s ? power : max_s;
         if (!ln) {
-            const double loud = -0.691 + 10.0 * log10(power);
-            if (loud >= -70.0) {
-                int b = static_cast<int>((loud - (-70.0)) * 100);
-                b = b < 0 ? 0 : (b > kEbuBins - 1 ? kEbuBins - 1 : b);
-                atomicAdd(&hh[b], 1u);
+            if (power >= ebu_edges[0]) {  // (as in k_block_hist)
+                atomicAdd(&hh[ebu_bin_from_edges(ebu_edges, power)], 1u);
                 sum_kept += power;
                 n_kept++;
             }
@@ -519,7 +527,8 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
 __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict__ tracks, int gate_mode,
                                                      const uint32_t *__restrict__ st_hist, const GatePart *__restrict__ parts,
                                                      const double *__restrict__ ln_bounds,
-                                                     const double *__restrict__ ln_energy, TrackOut *__restrict__ outs)
+                                                     const double *__restrict__ ln_energy,
+                                                     const double *__restrict__ ebu_edges, TrackOut *__restrict__ outs)
 {
     __shared__ double shd[256];
     __shared__ unsigned long long shu[256];
@@ -552,9 +561,7 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
             double rt = sum_kept / static_cast<double>(n_kept);
             if (!rt) rt = 1e-12;
             rel_energy = rt;
-            const double rel_thr = (-0.691 + 10.0 * log10(rt)) + (-20.0);
-            first = static_cast<int>((rel_thr - (-70.0)) * 100);
-            first = first < 0 ? 0 : (first > kEbuBins - 1 ? kEbuBins - 1 : first);
+            first = ebu_bin_from_edges(ebu_edges + 2 * kEbuBins, rt);  // the -20 LU gate's first bin (table 2 of the edges)
         }
     } else {
         double gs = 0;
@@ -623,15 +630,15 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
 
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
                         const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
-                        uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st)
+                        const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st)
 {
     if (!n_tracks) return;
     if (n_items)
         hipLaunchKernelGGL(k_range_stats, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, block_powers,
-                           ln_bounds, st_hist, parts);
+                           ln_bounds, ebu_edges, st_hist, parts);
     if (finalize)
         hipLaunchKernelGGL(k_range_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, st_hist, parts, ln_bounds, ln_energy,
-                       outs);
+                       ebu_edges, outs);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -807,20 +814,21 @@ void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint
 }
 
 void launch_block_hist(const TrackDesc *tracks, const WorkItem *items, uint32_t n_items, int gate_mode, const double *hop_sums,
-                       const double *ln_bounds, double *block_powers, uint32_t *hist, GatePart *parts, hipStream_t st)
+                       const double *ln_bounds, const double *ebu_edges, double *block_powers, uint32_t *hist, GatePart *parts,
+                       hipStream_t st)
 {
     if (!n_items) return;
-    hipLaunchKernelGGL(k_block_hist, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, ln_bounds,
+    hipLaunchKernelGGL(k_block_hist, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, ln_bounds, ebu_edges,
                        block_powers, hist, parts);
 }
 
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
-                       const uint32_t *hist, const double *ebu_energy, const double *ln_energy,
+                       const uint32_t *hist, const double *ebu_energy, const double *ebu_edges, const double *ln_energy,
                        const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st)
 {
     if (!n_tracks) return;
     hipLaunchKernelGGL(k_gate_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, block_powers, hist,
-                       ebu_energy, ln_energy, ln_bounds, parts, reduce_only ? 1 : 0, outs);
+                       ebu_energy, ebu_edges, ln_energy, ln_bounds, parts, reduce_only ? 1 : 0, outs);
 }
 
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,

@@ -334,6 +334,49 @@ const std::vector<double> &ebur128_bin_energy()
     return v;
 }
 
+// f_ebur128.c decides a histogram bin from a loudness it gets through log10():
+//     loud = -0.691 + 10*log10(power);  bin = clip((int)((loud - (-70)) * 100), 0, 8000)        (gate_update / HIST_POS)
+// and the two relative gates likewise from (loud + offset), offset = -10 LU (integrated) or -20 LU (range).  A device
+// log10 that differs from the host libm's by one ulp would move a value that sits on a bin edge into the neighbouring
+// bin, so the kernels never take a logarithm: these tables hold, for every bin b, the SMALLEST power whose bin (computed
+// with the host libm, the expression order above, contraction off) is >= b, and the kernels find the bin by comparing
+// powers.  Table 0: bins of block / window powers (entry 0 is the absolute gate: smallest power with loud >= -70);
+// tables 1, 2: first bin of the relative gates (entry 0 is 0: every mean power has a first bin).
+static int ebu_bin_of(double p, double offset, bool gate)
+{
+    const double loud = (-0.691 + 10.0 * std::log10(p)) + offset;
+    if (gate && !(loud >= -70.0)) return -1;
+    int b = static_cast<int>((loud - (-70.0)) * 100);
+    return b < 0 ? 0 : (b > 8000 ? 8000 : b);
+}
+
+const std::vector<double> &ebur128_bin_edges()
+{
+    static const std::vector<double> v = [] {
+        std::vector<double> e(3 * 8001);
+        const double offs[3] = {0.0, -10.0, -20.0};
+        for (int k = 0; k < 3; k++) {
+            const bool gate = k == 0;
+            for (int b = 0; b < 8001; b++) {
+                if (!gate && b == 0) { e[k * 8001 + b] = 0.0; continue; }
+                // the edge sits next to 10^((b/100 - 70 - offset + 0.691)/10): bracket it, then bisect on the doubles in between
+                const double guess = std::pow(10.0, (static_cast<double>(b) / 100.0 - 70.0 - offs[k] + 0.691) / 10.0);
+                double lo = guess * (1.0 - 1e-9), hi = guess * (1.0 + 1e-9);
+                while (ebu_bin_of(lo, offs[k], gate) >= b) lo *= 0.5;  // (never taken unless libm is far off)
+                while (ebu_bin_of(hi, offs[k], gate) < b) hi *= 2.0;
+                for (;;) {
+                    const double mid = lo + (hi - lo) * 0.5;
+                    if (!(mid > lo && mid < hi)) break;  // lo and hi are neighbouring doubles
+                    if (ebu_bin_of(mid, offs[k], gate) >= b) hi = mid; else lo = mid;
+                }
+                e[k * 8001 + b] = hi;
+            }
+        }
+        return e;
+    }();
+    return v;
+}
+
 const std::vector<double> &loudnorm_bin_energy()
 {
     static const std::vector<double> v = [] {

@@ -68,6 +68,9 @@ const double *bs1770_taps();
 
 // f_ebur128.c histogram bin energies: ENERGY(i/100 - 70), i < 8001
 const std::vector<double> &ebur128_bin_energy();
+// f_ebur128.c bin decisions without a device logarithm: three tables of 8001 powers (bins of a power; first bin of the
+// -10 LU gate; first bin of the -20 LU gate), entry b = smallest power that the host libm puts into bin >= b
+const std::vector<double> &ebur128_bin_edges();
 // libavfilter/ebur128.c tables: bin-centre energies [1000] and boundaries [1001]
 const std::vector<double> &loudnorm_bin_energy();
 const std::vector<double> &loudnorm_bin_bounds();

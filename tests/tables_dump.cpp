@@ -8,6 +8,10 @@
 
 int main(int argc, char **argv)
 {
+    if (argc > 1 && argv[1][0] == 'e') {  // "edges": the three f_ebur128 bin-edge tables, 3 x 8001 powers
+        for (double v : hr::ebur128_bin_edges()) std::printf("%.17g\n", v);
+        return 0;
+    }
     const uint32_t fs = argc > 1 ? std::atoi(argv[1]) : 48000;
     const hr::RateTables *rt = hr::rate_tables(fs);
     const hr::KCoef &k = rt->k;

@@ -202,6 +202,38 @@ def test_product_tables_match_oracle(oracle, fs):
     assert vals[9] < 1e-25  # |M^3|: the carry series is converged after three hops
 
 
+def test_ebur128_bin_edges_agree_with_the_libm_formula():
+    """The kernels decide f_ebur128's histogram bins (and the first bins of its -10 / -20 LU gates) by comparing powers
+    with host-built edges instead of taking a device log10.  Every edge must be exactly where the formula the oracle
+    evaluates (host libm, same expression order) changes its answer: a power one ulp below an edge -- 1e-16 relative --
+    lands in the lower bin, the edge itself in the upper one."""
+    vals = np.array(list(map(float, subprocess.check_output([_tables_exe(), "edges"]).decode().split())))
+    assert vals.size == 3 * 8001
+
+    def bin_of(p, offset, gate):
+        loud = (-0.691 + 10.0 * math.log10(p)) + offset
+        if gate and not loud >= -70.0:
+            return -1
+        return min(max(int((loud - (-70.0)) * 100), 0), 8000)
+
+    for k, off in enumerate((0.0, -10.0, -20.0)):
+        e = vals[k * 8001:(k + 1) * 8001]
+        assert np.all(np.diff(e) > 0)
+        for b in range(8001):
+            if k and b == 0:
+                assert e[0] == 0.0
+                continue
+            assert bin_of(e[b], off, k == 0) >= b, (k, b)
+            assert bin_of(np.nextafter(e[b], 0.0), off, k == 0) < b, (k, b)
+        # and in between the edges the kernel's search (largest b with edge[b] <= p) gives the formula's bin
+        rng = np.random.default_rng(5 + k)
+        ps = 10.0 ** rng.uniform(-8.5, 1.2, 4000)
+        for p in ps:
+            want = bin_of(p, off, k == 0)
+            got = int(np.searchsorted(e, p, side="right")) - 1 if p >= e[0] else -1
+            assert got == want, (k, p, got, want)
+
+
 def test_cpu_carry_algebra(oracle):
     """The zero-state + carry-correction algebra of k_hop_zero_state / k_hop_combine, on the host."""
     exe = "/tmp/hr_carry_check"
