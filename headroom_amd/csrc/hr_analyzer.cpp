@@ -7,9 +7,16 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <string>
 
 #include "../../include/headroom_hip.h"
+
+// No exception crosses the C ABI: every int-returning entry point is a function-try-block (std::bad_alloc from a host
+// container -> HR_ERR_OOM, anything else -> HR_ERR_INVALID).
+#ifndef HR_CATCH_ALL
+#define HR_CATCH_ALL catch (const std::bad_alloc &) { return HR_ERR_OOM; } catch (...) { return HR_ERR_INVALID; }
+#endif
 
 namespace {
 constexpr unsigned kHighBitrateThreshold = 256;  // analyzer.rs:26
@@ -27,7 +34,7 @@ double target_for(const hr_tp_target &m, bool is_lossy, bool has_bitrate, unsign
 
 extern "C" int hr_gain_decision(double input_i, double input_tp, int kind, int has_bitrate, uint32_t bitrate_kbps,
                                 const hr_tp_target *mode, hr_analysis *out)
-{
+try {
     if (!out || kind < HR_KIND_LOSSLESS || kind > HR_KIND_AAC) return HR_ERR_INVALID;
     hr_tp_target m{0, -0.5, -1.0};  // DEFAULT_TARGET_TRUE_PEAK, analyzer.rs:16
     if (mode) m = *mode;
@@ -69,7 +76,7 @@ extern "C" int hr_gain_decision(double input_i, double input_tp, int kind, int h
     }
     out->status = HR_OK;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 // What the reference actually holds after src/analyzer.rs:273-280: af_loudnorm prints `input_i` / `input_tp` with
 // "%.2f" (the fixture at src/analyzer.rs:370-371 shows the format) and the analyzer parses that text with
@@ -85,16 +92,16 @@ static double through_text_2dp(double v)
 }
 
 extern "C" int hr_loudnorm_text_values(const hr_result *r, double *input_i, double *input_tp)
-{
+try {
     if (!r) return HR_ERR_INVALID;
     if (input_i) *input_i = through_text_2dp(r->integrated_lufs);
     if (input_tp) *input_tp = through_text_2dp(r->true_peak_dbtp);
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 extern "C" int hr_gain_decision_for_result(const hr_result *r, int kind, int has_bitrate, uint32_t bitrate_kbps,
                                            const hr_tp_target *mode, hr_analysis *out)
-{
+try {
     if (!r || !out) return HR_ERR_INVALID;
     if (r->status != HR_OK) {  // the track failed to measure: the Err arm of analyze_file_with_target
         *out = hr_analysis{};
@@ -105,7 +112,7 @@ extern "C" int hr_gain_decision_for_result(const hr_result *r, int kind, int has
     double i = 0, tp = 0;
     hr_loudnorm_text_values(r, &i, &tp);
     return hr_gain_decision(i, tp, kind, has_bitrate, bitrate_kbps, mode, out);
-}
+} HR_CATCH_ALL
 
 // ---- report rows: src/report.rs:29-59 (CSV header and record), labels src/analyzer.rs:80-100 ---------------------
 namespace {
@@ -145,12 +152,12 @@ int emit(const std::string &s, char *buf, size_t cap)
 }  // namespace
 
 extern "C" int hr_report_csv_header(char *buf, size_t cap)
-{
+try {
     return emit("Filename,Format,Bitrate (kbps),LUFS,True Peak (dBTP),Target (dBTP),Headroom (dB),Method,Effective Gain (dB)\n", buf, cap);
-}
+} HR_CATCH_ALL
 
 extern "C" int hr_report_csv_row(const char *filename, const hr_analysis *a, char *buf, size_t cap)
-{
+try {
     if (!filename || !a) return HR_ERR_INVALID;
     char num[64];
     std::string o;
@@ -166,4 +173,4 @@ extern "C" int hr_report_csv_row(const char *filename, const hr_analysis *a, cha
     std::snprintf(num, sizeof num, ",%+.1f\n", a->effective_gain);
     o += num;
     return emit(o, buf, cap);
-}
+} HR_CATCH_ALL

@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <new>
 #include <limits>
 #include <mutex>
 #include <thread>
@@ -19,6 +20,12 @@
 #include "hr_device.hpp"
 #include "hr_kernels.hpp"
 #include "hr_tables.hpp"
+
+// No exception crosses the C ABI: every int-returning entry point is a function-try-block (std::bad_alloc from a host
+// container -> HR_ERR_OOM, anything else -> HR_ERR_INVALID).
+#ifndef HR_CATCH_ALL
+#define HR_CATCH_ALL catch (const std::bad_alloc &) { return HR_ERR_OOM; } catch (...) { return HR_ERR_INVALID; }
+#endif
 
 using namespace hr;
 
@@ -61,6 +68,7 @@ struct DevBuf {
     template <class T> T *as() const { return static_cast<T *>(p); }
 };
 
+constexpr size_t kMaxRatesPerCtx = 64;  // device tables are kept per distinct rate for the context's lifetime
 constexpr uint32_t kPeakSpan = 8192;  // positions per workgroup of the generic true-peak kernels
 constexpr uint32_t kTailSpan = 512;   // ... for the tail of a track whose body runs on the fused kernel
 
@@ -163,6 +171,10 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
 {
     for (size_t i = 0; i < ctx->rate_fs.size(); i++)
         if (ctx->rate_fs[i] == fs) return static_cast<int>(i);
+    if (ctx->rate_fs.size() >= kMaxRatesPerCtx) {
+        std::fprintf(stderr, "headroom_hip: more than %zu distinct sample rates on one context\n", kMaxRatesPerCtx);
+        return HR_ERR_RATE;
+    }
     const RateTables *rt = rate_tables(fs);
     if (!rt || rt->hop == 0) return HR_ERR_RATE;
     RateDev rd{};
@@ -216,7 +228,8 @@ int validate_track(const hr_ctx *ctx, const hr_track &t)
 {
     if (t.channels < 1 || t.channels > HR_MAX_CH) return HR_ERR_FORMAT;
     if (fmt_bytes(t.fmt) == 0) return HR_ERR_FORMAT;
-    if (t.sample_rate < 10) return HR_ERR_RATE;
+    // (the upper limit also bounds what rate_tables() builds per rate: O(sample_rate) doubles and work)
+    if (t.sample_rate < 10 || t.sample_rate > HR_MAX_SAMPLE_RATE) return HR_ERR_RATE;
     if (t.frames && !t.pcm) return HR_ERR_INVALID;
     if (ctx->cfg.tp_mode == HR_TP_SWR192K) {
         const RateTables *rt = rate_tables(t.sample_rate);
@@ -742,7 +755,7 @@ int hr_device_count(void)
 }
 
 int hr_init(const hr_config *cfg, hr_ctx **out)
-{
+try {
     if (!out) return HR_ERR_INVALID;
     *out = nullptr;
     hr_config c{};
@@ -791,7 +804,7 @@ int hr_init(const hr_config *cfg, hr_ctx **out)
     if (rc) { hr_destroy(ctx); return rc; }
     *out = ctx;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 void hr_destroy(hr_ctx *ctx)
 {
@@ -822,9 +835,10 @@ void *hr_alloc_pinned(size_t bytes)
 void hr_free_pinned(void *p) { if (p) (void)hipHostFree(p); }
 
 int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out)
-{
+try {
     if (!ctx || (n && (!tracks || !out))) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
     ctx->last_total_ms = ctx->last_main_ms = 0;
     const double ninf = -std::numeric_limits<double>::infinity();
@@ -861,10 +875,10 @@ int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *o
     }
     flush();
     return fatal;
-}
+} HR_CATCH_ALL
 
 int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out)
-{
+try {
     if (!ctx || !track || !out) return HR_ERR_INVALID;
     if (!(track->flags & HR_TRACK_DEVICE_PCM)) return HR_ERR_INVALID;  // a host buffer would need a staging allocation
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -891,15 +905,23 @@ int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out
     arena.base = static_cast<char *>(g_scratch_ptr[dev]);
     arena.cap = kScratchBytes;
     // the context's own workspace steps aside for the call; every buffer is carved from the array instead
-    const std::vector<DevBuf *> ws = ctx->workspace();
-    std::vector<DevBuf> saved;
-    saved.reserve(ws.size());
-    for (DevBuf *b : ws) {
-        saved.push_back(*b);
-        *b = DevBuf{};
-        b->arena = &arena;
-    }
-    ctx->no_alloc = true;
+    struct Swap {  // (restores the context's buffers on every way out, an exception included)
+        hr_ctx *ctx;
+        std::vector<DevBuf *> ws;
+        std::vector<DevBuf> saved;
+        Swap(hr_ctx *c, Arena *a) : ctx(c), ws(c->workspace())
+        {
+            saved.reserve(ws.size());
+            for (DevBuf *b : ws) saved.push_back(*b);
+            for (DevBuf *b : ws) { *b = DevBuf{}; b->arena = a; }
+            ctx->no_alloc = true;
+        }
+        ~Swap()
+        {
+            ctx->no_alloc = false;
+            for (size_t i = 0; i < ws.size(); i++) *ws[i] = saved[i];
+        }
+    } swap(ctx, &arena);
     ctx->shard_open = false;  // an open time shard's workspace is not the one pass 2 would find
     ctx->last_total_ms = ctx->last_main_ms = 0;
     std::memset(out, 0, sizeof *out);
@@ -907,18 +929,17 @@ int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out
     out->loudness_range_lu = out->lra_low_lufs = out->lra_high_lufs = out->lra_threshold_lufs = out->max_momentary_lufs =
         out->max_shortterm_lufs = std::numeric_limits<double>::quiet_NaN();
     int rc = analyze_group(ctx, track, std::vector<size_t>{0}, out);
-    ctx->no_alloc = false;
-    for (size_t i = 0; i < ws.size(); i++) *ws[i] = saved[i];
     if (rc == HR_ERR_OOM) rc = HR_ERR_TOO_LARGE;  // the array was too small after all (the limit above is meant to exclude this)
     if (rc) out->status = rc;
     return rc;
-}
+} HR_CATCH_ALL
 
 int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint64_t cap_hops, double *block_powers,
                       uint64_t cap_blocks, uint64_t *n_hops, uint64_t *n_blocks)
-{
+try {
     if (!ctx || !track) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
     const int v = validate_track(ctx, *track);
     if (v) return v;
@@ -954,7 +975,7 @@ int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint
     }
     HIPCHK(hipStreamSynchronize(st));
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 static double raw_to_double(const unsigned char *p, int fmt)
 {
@@ -974,7 +995,7 @@ static double raw_to_double(const unsigned char *p, int fmt)
 }
 
 int hr_shard_head(hr_ctx *ctx, const hr_track *shard, double *head)
-{
+try {
     if (!ctx || !shard || !head) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->cfg.device));
@@ -992,14 +1013,15 @@ int hr_shard_head(hr_ctx *ctx, const hr_track *shard, double *head)
         for (int c = 0; c < HR_MAX_CH; c++)
             head[k * HR_MAX_CH + c] = (static_cast<uint64_t>(k) < tf && c < C) ? raw_to_double(raw.data() + (k * C + c) * fb, shard->fmt) : 0.0;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
                    int is_last, uint64_t first_hop, hr_shard_edge *edge)
-{
+try {
     if (!ctx || !shard || !edge) return HR_ERR_INVALID;
     if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->shard_open = false;  // (set again at the end, once the new shard's workspace is complete)
     HIPCHK(hipSetDevice(ctx->cfg.device));
     if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
     const int v = validate_track(ctx, *shard);
@@ -1079,10 +1101,10 @@ int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, 
         }
     ctx->shard_open = true;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *partial)
-{
+try {
     if (!ctx || !partial) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
     if (!ctx->shard_open || !ctx->shard_group) return HR_ERR_INVALID;
@@ -1153,12 +1175,13 @@ int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *par
     partial->range_ok = range_ok ? 1 : 0;
     ctx->shard_open = false;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_result *out)
-{
+try {
     if (!ctx || !red || !out || channels < 1 || channels > HR_MAX_CH) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
     if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
     hipStream_t st = ctx->stream;
@@ -1203,15 +1226,18 @@ int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *red, int channels, hr_r
     std::memset(out, 0, sizeof *out);
     fill_result(ctx, o, pk, channels, out, red->range_ok != 0);
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 // Config 5 inside one process: one context per GPU, the exchange steps on the host (a few KB).
 int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *track, hr_result *out)
-{
+try {
     if (!ctxs || n_ctx < 1 || !track || !out) return HR_ERR_INVALID;
     for (int i = 0; i < n_ctx; i++)
         if (!ctxs[i] || ctxs[i]->cfg.gate_mode != ctxs[0]->cfg.gate_mode || ctxs[i]->cfg.tp_mode != ctxs[0]->cfg.tp_mode)
             return HR_ERR_INVALID;
+    for (int i = 0; i < n_ctx; i++)
+        for (int j = 0; j < i; j++)
+            if (ctxs[i] == ctxs[j]) return HR_ERR_INVALID;  // one context holds ONE open shard between pass 1 and pass 2
     const int v = validate_track(ctxs[0], *track);
     if (v) return v;
     if (track->flags & HR_TRACK_DEVICE_PCM)  // a device pointer belongs to one GPU: all contexts must sit on it
@@ -1277,12 +1303,13 @@ int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *tr
         red.range_ok = r == 0 ? part[r].range_ok : std::min(red.range_ok, part[r].range_ok);
     }
     return hr_shard_finish(ctxs[0], &red, track->channels, out);
-}
+} HR_CATCH_ALL
 
 int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out)
-{
+try {
     if (!ctx || (n && (!tracks || !out))) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
     ctx->last_total_ms = ctx->last_main_ms = 0;
     hipStream_t st = ctx->stream;
@@ -1311,7 +1338,7 @@ int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_res
             int v = HR_OK;
             const RateTables *rt = nullptr;
             if (t.channels < 1 || t.channels > HR_MAX_CH || fmt_bytes(t.fmt) == 0) v = HR_ERR_FORMAT;
-            else if (t.sample_rate < 10 || !(rt = rate_tables(t.sample_rate)) || rt->swr_phases < 0 ||
+            else if (t.sample_rate < 10 || t.sample_rate > HR_MAX_SAMPLE_RATE || !(rt = rate_tables(t.sample_rate)) || rt->swr_phases < 0 ||
                      (rt->swr_phases == 0 && t.sample_rate != 192000)) v = HR_ERR_RATE;
             else if (t.frames && !t.pcm) v = HR_ERR_INVALID;
             if (v) { out[j].status = v; continue; }
@@ -1381,13 +1408,14 @@ int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_res
     }
     ctx->cfg = saved;
     return fatal;
-}
+} HR_CATCH_ALL
 
 int hr_apply_gain(hr_ctx *ctx, const hr_track *track, double gain_db, int out_big_endian, void *out, uint64_t *clipped)
-{
+try {
     if (!ctx || !track || (track->frames && (!track->pcm || !out)) || !std::isfinite(gain_db)) return HR_ERR_INVALID;
     if (track->channels < 1 || track->channels > HR_MAX_CH || fmt_bytes(track->fmt) == 0) return HR_ERR_FORMAT;
     std::lock_guard<std::mutex> lk(ctx->mu);
+    ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
     hipStream_t st = ctx->stream;
     const uint64_t n = track->frames * track->channels;
@@ -1416,10 +1444,10 @@ int hr_apply_gain(hr_ctx *ctx, const hr_track *track, double gain_db, int out_bi
     HIPCHK(hipStreamSynchronize(st));
     if (clipped) *clipped = c;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_rate, uint32_t channels, uint64_t frames)
-{
+try {
     if (!ctx || !device_pcm || channels < 1 || channels > HR_MAX_CH || sample_rate < 10) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
     HIPCHK(hipSetDevice(ctx->cfg.device));
@@ -1429,15 +1457,15 @@ int hr_synth_fill(hr_ctx *ctx, void *device_pcm, uint64_t seed, uint32_t sample_
     HIPCHK(hipGetLastError());
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 int hr_last_timing(hr_ctx *ctx, float *total_ms, float *main_kernel_ms)
-{
+try {
     if (!ctx) return HR_ERR_INVALID;
     if (total_ms) *total_ms = ctx->last_total_ms;
     if (main_kernel_ms) *main_kernel_ms = ctx->last_main_ms;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 const char *hr_strerror(int code)
 {

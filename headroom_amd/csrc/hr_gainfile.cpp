@@ -6,10 +6,17 @@
 // purpose: keep bext, ID3 and the like).  Built on the public C ABI only.
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <string>
 #include <vector>
 
 #include "../../include/headroom_hip.h"
+
+// No exception crosses the C ABI: every int-returning entry point is a function-try-block (std::bad_alloc from a host
+// container -> HR_ERR_OOM, anything else -> HR_ERR_INVALID).
+#ifndef HR_CATCH_ALL
+#define HR_CATCH_ALL catch (const std::bad_alloc &) { return HR_ERR_OOM; } catch (...) { return HR_ERR_INVALID; }
+#endif
 
 namespace {
 
@@ -47,7 +54,7 @@ bool read_file(const char *path, std::vector<uint8_t> &out)
 }  // namespace
 
 extern "C" int hr_pcm_gain_file(hr_ctx *ctx, const char *path, double gain_db, uint64_t *clipped)
-{
+try {
     if (!ctx || !path) return HR_ERR_INVALID;
     std::vector<uint8_t> file;
     if (!read_file(path, file)) return HR_ERR_INVALID;
@@ -169,4 +176,4 @@ extern "C" int hr_pcm_gain_file(hr_ctx *ctx, const char *path, double gain_db, u
         return HR_ERR_INVALID;
     }
     return HR_OK;
-}
+} HR_CATCH_ALL

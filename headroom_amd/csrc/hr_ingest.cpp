@@ -15,10 +15,17 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <new>
 #include <vector>
 
 #include "../../include/headroom_hip.h"
 #include "hr_tables.hpp"
+
+// No exception crosses the C ABI: every int-returning entry point is a function-try-block (std::bad_alloc from a host
+// container -> HR_ERR_OOM, anything else -> HR_ERR_INVALID).
+#ifndef HR_CATCH_ALL
+#define HR_CATCH_ALL catch (const std::bad_alloc &) { return HR_ERR_OOM; } catch (...) { return HR_ERR_INVALID; }
+#endif
 
 namespace {
 
@@ -47,20 +54,6 @@ int pcm_fmt(bool is_float, int bits)
 
 int bytes_of(int fmt) { return fmt == HR_FMT_S16 ? 2 : fmt == HR_FMT_S24 ? 3 : fmt == HR_FMT_F64 ? 8 : 4; }
 
-// WAVE_FORMAT_EXTENSIBLE speaker bits -> loudness weight (BS.1770: surrounds 1.41, LFE excluded; FFmpeg f_ebur128.c)
-void weights_from_mask(uint32_t mask, int channels, float *w)
-{
-    int c = 0;
-    for (int bit = 0; bit < 18 && c < channels; bit++) {
-        if (!(mask & (1u << bit))) continue;
-        const uint32_t sp = 1u << bit;
-        const bool lfe = sp == 0x8;
-        const bool surround = sp == 0x10 || sp == 0x20 || sp == 0x200 || sp == 0x400;  // BL BR SL SR
-        w[c++] = lfe ? 0.0f : surround ? 1.41f : 1.0f;
-    }
-    for (; c < channels; c++) w[c] = 1.0f;
-}
-
 // b[0..n) is a prefix of a file of `total` bytes: chunk headers must lie inside the prefix, sample data need not
 int probe_wav(const uint8_t *b, size_t n, uint64_t total, hr_pcm_info *o)
 {
@@ -75,7 +68,7 @@ int probe_wav(const uint8_t *b, size_t n, uint64_t total, hr_pcm_info *o)
             int tag = le16(b + body);
             o->channels = le16(b + body + 2);
             o->sample_rate = le32(b + body + 4);
-            if (o->sample_rate == 0) return HR_ERR_RATE;
+            if (o->sample_rate == 0 || o->sample_rate > HR_MAX_SAMPLE_RATE) return HR_ERR_RATE;
             const int bits = le16(b + body + 14);
             o->channel_mask = 0;
             if (tag == 0xFFFE) {
@@ -118,7 +111,7 @@ int probe_aiff(const uint8_t *b, size_t n, uint64_t total, hr_pcm_info *o)
             comm_frames = be32(b + body + 2);
             const int bits = be16(b + body + 6);
             const double rate = be_extended(b + body + 8);
-            if (!(rate >= 1.0 && rate <= 4294967295.0)) return HR_ERR_RATE;
+            if (!(rate >= 1.0 && rate <= static_cast<double>(HR_MAX_SAMPLE_RATE))) return HR_ERR_RATE;
             o->sample_rate = static_cast<uint32_t>(std::llround(rate));
             bool is_float = false;
             o->big_endian = 1;
@@ -171,13 +164,13 @@ static int probe_any(const uint8_t *b, size_t n, uint64_t total, hr_pcm_info *in
 }
 
 int hr_pcm_probe(const void *file_bytes, size_t n, hr_pcm_info *info)
-{
+try {
     if (!file_bytes || !info) return HR_ERR_INVALID;
     return probe_any(static_cast<const uint8_t *>(file_bytes), n, n, info);
-}
+} HR_CATCH_ALL
 
 int hr_pcm_load_file(const char *path, void **pcm_out, hr_track *track, float *weights)
-{
+try {
     if (!path || !pcm_out || !track || !weights) return HR_ERR_INVALID;
     *pcm_out = nullptr;
     std::FILE *f = std::fopen(path, "rb");
@@ -213,7 +206,7 @@ int hr_pcm_load_file(const char *path, void **pcm_out, hr_track *track, float *w
         for (uint64_t i = 0; i + w <= bytes; i += w)
             for (int a = 0, z = w - 1; a < z; a++, z--) std::swap(p[i + a], p[i + z]);
     }
-    if (info.channel_mask) weights_from_mask(info.channel_mask, info.channels, weights);
+    if (info.channel_mask) hr::weights_from_mask(info.channel_mask, info.channels, weights);
     else hr::default_weights(info.channels, weights);
     std::memset(track, 0, sizeof *track);
     track->pcm = buf;
@@ -224,6 +217,6 @@ int hr_pcm_load_file(const char *path, void **pcm_out, hr_track *track, float *w
     track->ch_weight = weights;
     *pcm_out = buf;
     return HR_OK;
-}
+} HR_CATCH_ALL
 
 }  // extern "C"

@@ -40,12 +40,29 @@ KCoef kweight_coeffs(double fs)
     return c;
 }
 
+// f_ebur128.c config_audio_output: a channel's loudness weight follows its speaker position -- LFE 0 (skipped), every
+// back / side / top-back speaker (its BACK_MASK: BL BR BC SL SR TBL TBC TBR) 1.41, the rest 1.0.  Bits as in
+// WAVE_FORMAT_EXTENSIBLE's dwChannelMask = FFmpeg's AV_CH_* (bit 0 = FL ... bit 17 = TBR).
+void weights_from_mask(uint32_t mask, int channels, float *w)
+{
+    constexpr uint32_t kLfe = 0x8;
+    constexpr uint32_t kBackMask = 0x10 | 0x20 | 0x100 | 0x200 | 0x400 | 0x8000 | 0x10000 | 0x20000;
+    int c = 0;
+    for (int bit = 0; bit < 32 && c < channels; bit++) {
+        const uint32_t sp = 1u << bit;
+        if (!(mask & sp)) continue;
+        w[c++] = sp == kLfe ? 0.0f : (sp & kBackMask) ? 1.41f : 1.0f;
+    }
+    for (; c < channels; c++) w[c] = 1.0f;
+}
+
+// No layout given: FFmpeg assigns the default layout of the channel count (av_channel_layout_default): mono, stereo,
+// 2.1 (FL FR LFE), 4.0 (FL FR FC BC), 5.0 (FL FR FC BL BR), 5.1 (FL FR FC LFE BL BR), 6.1 (FL FR FC LFE BC SL SR),
+// 7.1 (FL FR FC LFE BL BR SL SR).
 void default_weights(int channels, float *w)
 {
-    for (int c = 0; c < channels; c++) w[c] = 1.0f;
-    if (channels == 6) { w[3] = 0.0f; w[4] = 1.41f; w[5] = 1.41f; }       // L R C LFE Ls Rs
-    else if (channels == 5) { w[3] = 1.41f; w[4] = 1.41f; }               // L R C Ls Rs
-    else if (channels == 4) { w[2] = 1.41f; w[3] = 1.41f; }               // L R Ls Rs
+    static const uint32_t kDefaultMask[9] = {0, 0x4, 0x3, 0x3 | 0x8, 0x7 | 0x100, 0x7 | 0x30, 0xF | 0x30, 0xF | 0x100 | 0x600, 0xF | 0x30 | 0x600};
+    weights_from_mask(channels >= 1 && channels <= 8 ? kDefaultMask[channels] : 0, channels, w);
 }
 
 static double bessel_i0(double x)

@@ -75,6 +75,9 @@ const std::vector<double> &ebur128_bin_edges();
 const std::vector<double> &loudnorm_bin_energy();
 const std::vector<double> &loudnorm_bin_bounds();
 
+// loudness weight per channel from a speaker mask (WAVE dwChannelMask / AV_CH_* bits), and for FFmpeg's default layout of
+// a channel count
+void weights_from_mask(uint32_t mask, int channels, float *w);
 void default_weights(int channels, float *w);
 
 uint16_t f32_to_f16_rn(float f);

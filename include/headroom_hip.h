@@ -20,6 +20,7 @@ extern "C" {
 #endif
 
 #define HR_MAX_CH 8
+#define HR_MAX_SAMPLE_RATE 768000u /* higher rates: HR_ERR_RATE (per-rate tables are O(rate); a crafted header cannot ask for more) */
 
 /* error codes (0 = ok, < 0 = error); also used in hr_result.status */
 enum {
@@ -149,6 +150,9 @@ int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint
  * on its shard, hands its hr_shard_edge to the right neighbour, runs pass2 with the edge it got
  * from the left, and the hr_shard_partial records are all-reduced (sum; max for the peaks) before
  * hr_shard_finish.  HR_GATE_EXACT needs a second reduction and is not offered here.
+ * A context holds ONE open shard: pass 2 reads the workspace pass 1 left in the context, so any other call on that
+ * context in between (hr_analyze_batch, hr_block_energies, hr_apply_gain, hr_loudnorm_first_pass, another pass 1, ...)
+ * closes the shard and its hr_shard_pass2 then returns HR_ERR_INVALID.
  * No counterpart in the reference: ffmpeg handles a file strictly sequentially. */
 typedef struct hr_shard_edge {
     /* zero-state records of the shard's last 6 hops, oldest first, per channel:

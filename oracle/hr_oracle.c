@@ -60,18 +60,21 @@ void hro_kweight_coeffs(double fs, hro_kcoef *k)
 
 void hro_default_weights(int channels, float *w)
 {
-    for (int c = 0; c < channels; c++) w[c] = 1.0f;
-    if (channels == 6) { /* 5.1: L R C LFE Ls Rs (f_ebur128.c: LFE -> 0, back/side -> 1.41) */
-        w[3] = 0.0f;
-        w[4] = 1.41f;
-        w[5] = 1.41f;
-    } else if (channels == 5) { /* 5.0: L R C Ls Rs */
-        w[3] = 1.41f;
-        w[4] = 1.41f;
-    } else if (channels == 4) { /* quad: L R Ls Rs */
-        w[2] = 1.41f;
-        w[3] = 1.41f;
-    }
+    /* f_ebur128.c: LFE -> 0, back / side speakers -> 1.41, others 1.0, on FFmpeg's default layout of the channel
+     * count: 2.1 = FL FR LFE; 4.0 = FL FR FC BC; 5.0 = FL FR FC BL BR; 5.1 = FL FR FC LFE BL BR;
+     * 6.1 = FL FR FC LFE BC SL SR; 7.1 = FL FR FC LFE BL BR SL SR */
+    static const float tab[9][8] = {
+        {0},
+        {1.0f},
+        {1.0f, 1.0f},
+        {1.0f, 1.0f, 0.0f},
+        {1.0f, 1.0f, 1.0f, 1.41f},
+        {1.0f, 1.0f, 1.0f, 1.41f, 1.41f},
+        {1.0f, 1.0f, 1.0f, 0.0f, 1.41f, 1.41f},
+        {1.0f, 1.0f, 1.0f, 0.0f, 1.41f, 1.41f, 1.41f},
+        {1.0f, 1.0f, 1.0f, 0.0f, 1.41f, 1.41f, 1.41f, 1.41f},
+    };
+    for (int c = 0; c < channels; c++) w[c] = (channels >= 1 && channels <= 8) ? tab[channels][c] : 1.0f;
 }
 
 double hro_sample(const void *pcm, int fmt, uint64_t idx)

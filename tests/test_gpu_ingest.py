@@ -45,6 +45,21 @@ def test_wav_5_1_extensible_uses_the_channel_mask(oracle, tmp_path):
         _check(oracle, m, p, seen, fs, 6, hr.FMT_S24, weights=np.array([1, 1, 1, 0, 1.41, 1.41], dtype=np.float32))
 
 
+def test_channel_mask_weights_cover_ffmpegs_back_mask(tmp_path):
+    """Every speaker of f_ebur128's BACK_MASK gets 1.41 (BL BR BC SL SR TBL TBC TBR), LFE 0, the rest 1."""
+    fs = 48000
+    pcm = signals.seeded_noise(45, 4800, 8, -20.0).astype(np.float64)
+    # FL FR FC LFE BC(0x100) SL SR TBC(0x10000); then FL FR BL BR TFL(0x1000) TFR(0x4000) TBL(0x8000) TBR(0x20000)
+    for mask, want in ((0x7 | 0x8 | 0x100 | 0x600 | 0x10000, [1, 1, 1, 0, 1.41, 1.41, 1.41, 1.41]),
+                       (0x3 | 0x30 | 0x1000 | 0x4000 | 0x8000 | 0x20000, [1, 1, 1.41, 1.41, 1, 1, 1.41, 1.41])):
+        data, _ = containers.wav_bytes(pcm, fs, "s16", extensible_mask=mask)
+        p = tmp_path / f"m{mask:x}.wav"
+        p.write_bytes(data)
+        f = hr.LoadedFile(str(p))
+        assert [round(float(f.weights[c]), 2) for c in range(8)] == want, hex(mask)
+        f.close()
+
+
 @pytest.mark.parametrize("kind,aifc,fmt", [("s16", None, hr.FMT_S16), ("s24", None, hr.FMT_S24), ("s16", b"sowt", hr.FMT_S16),
                                             ("f32", b"fl32", hr.FMT_F32)])
 def test_aiff_files(oracle, tmp_path, kind, aifc, fmt):

@@ -145,6 +145,18 @@ def test_formats_and_channel_counts(oracle, meters, engine):
 
 
 @pytest.mark.parametrize("engine", [0, 1])
+def test_default_layout_weights_known_answers(oracle, meters, engine):
+    """NULL ch_weight = f_ebur128's weights on FFmpeg's default layout of the channel count (2.1, 4.0, 5.0, 5.1, 6.1,
+    7.1): a tone in one channel at a time reads its analytic value through the C ABI (LFE: -inf), and equals the oracle."""
+    import test_oracle_kat as kat
+    m = meters(engine=engine)
+    rows = kat.one_channel_answers(lambda pcm, fs: m.analyze(pcm, fs))
+    kat.check_one_channel_answers(rows)
+    for (ch, c, w, lufs), (_, _, _, ref) in zip(rows, kat.one_channel_answers(oracle.measure)):
+        assert lufs == ref or abs(lufs - ref) < 1e-6, (ch, c)
+
+
+@pytest.mark.parametrize("engine", [0, 1])
 def test_edge_cases(oracle, meters, engine):
     m = meters(engine=engine)
     fs = 48000
@@ -188,6 +200,18 @@ def test_batch_order_errors_and_device_pcm(oracle, meters):
         assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
         assert got["peak_per_ch"] == ref["peak_per_ch"]
     assert m.analyze_batch([]) == []
+
+
+def test_sample_rate_limit_and_no_exception_across_the_abi(meters):
+    """fs = 0xFFFFFFFF once made rate_tables() allocate ~40 GB (or throw across the C ABI); now HR_ERR_RATE per track,
+    from both batch entry points, without touching the PCM."""
+    m = meters()
+    x = np.zeros((4800, 2), dtype=np.float32)
+    for fs in (0xFFFFFFFF, 768001):
+        got = m.analyze_batch([hr.TrackSpec(x, fs)])[0]
+        assert got["status"] == hr.ERR_RATE
+        assert m.loudnorm_first_pass([hr.TrackSpec(x, fs)])[0]["status"] == hr.ERR_RATE
+    assert m.analyze_batch([hr.TrackSpec(x, 48000)])[0]["status"] == 0
 
 
 def test_small_staging_splits_batch(oracle):
@@ -267,6 +291,22 @@ def test_time_shards_equal_whole_stream(oracle, meters):
         assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
         # the middle shard has 7 hops: too short to hand 29 hop energies on, so the range statistics are withheld
         assert [e.range_ok for e in edges] == [0, 0, 1] and all(math.isnan(got[k]) for k in RANGE_KEYS)
+
+
+def test_a_call_between_the_shard_passes_closes_the_shard(meters):
+    fs = 48000
+    pcm = signals.seeded_noise(78, 4800 * 12, 2, -17.0)
+    with hr.Meter() as m:
+        spec = hr.TrackSpec(pcm, fs)
+        m.shard_pass1(spec, None, None)
+        m.analyze(pcm[: 4800 * 3], fs)              # reuses the context's workspace
+        with pytest.raises(hr.HeadroomError) as e:
+            m.shard_pass2(None)
+        assert e.value.code == hr.ERR_INVALID
+        m.shard_pass1(spec, None, None)             # and the pair still works when nothing comes between
+        m.shard_pass2(None)
+        with pytest.raises(hr.HeadroomError):       # the same context twice in one sharded call
+            hr.analyze_stream_sharded([m, m], spec)
 
 
 def test_full_size_track_properties(oracle, meters):

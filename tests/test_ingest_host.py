@@ -88,3 +88,15 @@ def test_aiff_ssnd_offset_and_chunk_order():
 def test_aiff_compressed_is_rejected():
     data, _ = containers.aiff_bytes(_pcm(10, 2), 44100, "s16", aifc=b"ima4")
     assert hr.pcm_probe(data)[0] == hr.ERR_FORMAT
+
+
+def test_absurd_sample_rates_are_rejected_before_any_table_is_built():
+    """A crafted header must not make the library build O(rate) tables: rates above HR_MAX_SAMPLE_RATE (768 kHz) are
+    refused by the probe (and by validate_track on the GPU side: tests/test_gpu_parity.py)."""
+    import struct
+    data, _ = containers.wav_bytes(_pcm(100, 2), 48000, "s16")
+    for rate, want in ((0xFFFFFFFF, hr.ERR_RATE), (768001, hr.ERR_RATE), (768000, hr.OK)):
+        bad = bytearray(data)
+        bad[24:28] = struct.pack("<I", rate)  # nSamplesPerSec of the fmt chunk
+        rc, info = hr.pcm_probe(bytes(bad))
+        assert rc == want, rate

@@ -200,6 +200,39 @@ def test_lfe_excluded_from_loudness_but_not_from_peak(oracle):
     assert abs(r["true_peak_dbtp"] - (-3.0)) < 0.05
 
 
+# FFmpeg's default layout of each channel count and f_ebur128's weights on it (LFE 0, back / side speakers 1.41)
+DEFAULT_LAYOUT_WEIGHTS = {1: [1], 2: [1, 1], 3: [1, 1, 0], 4: [1, 1, 1, 1.41], 5: [1, 1, 1, 1.41, 1.41],
+                          6: [1, 1, 1, 0, 1.41, 1.41], 7: [1, 1, 1, 0, 1.41, 1.41, 1.41], 8: [1, 1, 1, 0, 1.41, 1.41, 1.41, 1.41]}
+
+
+def one_channel_answers(measure, fs=48000):
+    """A -23 dBFS 1 kHz sine in ONE channel of a default-layout track reads -23 - 3.01 + 10 log10(weight) LUFS
+    (a sine of A dBFS in one channel: mean square A - 3.01 dB, K-gain at 1 kHz +0.69 cancels the -0.691), and -inf
+    when the channel is the LFE.  Returns [(channels, channel, weight, lufs)]."""
+    tone = signals.sine(fs, 1000.0, -23.0, 6.0)
+    out = []
+    for ch, ws in DEFAULT_LAYOUT_WEIGHTS.items():
+        for c, w in enumerate(ws):
+            pcm = np.zeros((tone.size, ch), dtype=np.float32)
+            pcm[:, c] = tone
+            out.append((ch, c, w, measure(pcm, fs)["integrated_lufs"]))
+    return out
+
+
+def check_one_channel_answers(rows):
+    for ch, c, w, lufs in rows:
+        if w == 0:
+            assert lufs == -math.inf, (ch, c)                     # LFE: excluded from loudness altogether
+        else:
+            assert abs(lufs - (-23.0 - 3.0103 + 10 * math.log10(w))) < 0.02, (ch, c, w, lufs)
+
+
+def test_default_layout_weights_per_channel_count(oracle):
+    for ch, ws in DEFAULT_LAYOUT_WEIGHTS.items():
+        assert list(oracle.default_weights(ch)) == [np.float32(w) for w in ws], ch
+    check_one_channel_answers(one_channel_answers(oracle.measure))   # 7.1: signal only in LFE -> -inf, only in SL -> +1.49 dB
+
+
 def test_loudnorm_path(oracle):
     # af_loudnorm measures after resampling to 192 kHz; on a 1 kHz sine it agrees with the native-rate meter
     x = signals.stereo(signals.sine(48000, 1000.0, -20.0, 6.0))
