@@ -78,6 +78,9 @@ def main():
                          "stereo f32 planes on the device, then the same fused kernel); config5 = one 10-hour 48 kHz stereo stream, "
                          "whole and as 8 time shards on this one device (a side figure)")
     ap.add_argument("--hours", type=float, default=10.0, help="config5: length of the stream")
+    ap.add_argument("--total-tracks", type=int, default=0,
+                    help="config3 with --gpus N > 1 (or this flag): the whole batch is this many tracks (default 10000 = BASELINE "
+                         "configs[2]) split over the ranks by bytes, strong scaling")
     ap.add_argument("--host-pcm", type=int, default=0, metavar="N",
                     help="also time N tracks handed over as pinned HOST buffers (PCIe-inclusive; reported beside, never as value)")
     args = ap.parse_args()
@@ -116,8 +119,16 @@ def main():
         meter.close()
         return
     if args.workload == "config5":
-        run_config5(args, meter, dev, local)
+        run_config5(args, meter, dev, local, rank, world, rehearsal)
         meter.close()
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    if args.workload == "config3" and (world > 1 or args.total_tracks):
+        run_config3_strong(args, meter, dev, rank, world, rehearsal)
+        meter.close()
+        if world > 1:
+            dist.destroy_process_group()
         return
     frames = FS * SECONDS
     # HR_BENCH_OFFSET (experiments): byte offset of every track inside its slot, to see what cache-line alignment is worth
@@ -269,15 +280,74 @@ def run_config4(args, meter, dev, n_tracks, rank):
                       "hbm_gbs_whole_step": nbytes / dt / 1e9, "sample_result": res[0]}), flush=True)
 
 
-def run_config5(args, meter, dev, local):
-    """BASELINE configs[4] on ONE device: a single long 48 kHz stereo f32 stream, analysed whole (one track) and as 8
-    time shards through hr_analyze_stream_sharded (8 contexts on this device: carry hand-off, boundary blocks, halos
-    and the histogram reduction are all exercised; only the GPUs are not distinct)."""
+def _dist_max(value, world, rehearsal, dev):
+    """MAX over ranks of a host float (the timing all-reduce: RCCL on the GPUs, gloo in the one-device rehearsal)."""
+    if world == 1:
+        return value
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if rehearsal else dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def _dist_barrier(world):
+    import torch
+    torch.cuda.synchronize()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    torch.cuda.synchronize()
+
+
+def run_config5(args, meter, dev, local, rank=0, world=1, rehearsal=False):
+    """BASELINE configs[4]: a single long 48 kHz stereo f32 stream.
+
+    One rank: analysed whole (one track) and as 8 time shards through hr_analyze_stream_sharded (8 contexts on this
+    device: carry hand-off, boundary blocks, halos and the histogram reduction are all exercised; only the GPUs are not
+    distinct).  N ranks (torch.distributed.run): the stream is cut into N hop-aligned time shards, rank r holds shard r in
+    its own HBM and runs headroom_amd.sharded.analyze_stream_shard -- pass 1, halo + edge exchange with the
+    neighbours, pass 2, all-reduce of the gating partial, finish -- over RCCL ("nccl"); strong scaling (the stream's
+    length is fixed), per-phase wall times reported as the maximum over ranks.  The shards are generated on the device,
+    each from its own seed: the stream is their concatenation."""
     import torch
 
     import headroom_amd as hr
+    from headroom_amd import sharded
     fs, ch = 48000, 2
     frames = int(args.hours * 3600) * fs
+    if world > 1:
+        import torch.distributed as dist
+        cuts = sharded.cut_stream(frames, fs, world)
+        active = sharded.active_shards(cuts)
+        n = cuts[rank + 1] - cuts[rank]
+        spec = None
+        if n > 0:
+            pcm = torch.empty((n, ch), dtype=torch.float32, device=dev)
+            meter.synth_fill(pcm.data_ptr(), 77 + rank, fs, ch, n)
+            spec = hr.TrackSpec(pcm.data_ptr(), fs, channels=ch, fmt=hr.FMT_F32, frames=n)
+        torch.cuda.synchronize()
+        for _ in range(args.warmup):
+            res = sharded.analyze_stream_shard(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10))
+        phases = {}
+        _dist_barrier(world)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = sharded.analyze_stream_shard(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10), timings=phases)
+        _dist_barrier(world)
+        elapsed = _dist_max(time.perf_counter() - t0, world, rehearsal, dev)
+        phase_ms = {k: _dist_max(v, world, rehearsal, dev) / args.steps * 1e3 for k, v in sorted(phases.items())}
+        if rank == 0:
+            dt = elapsed / args.steps
+            print(json.dumps({
+                "metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": args.hours / dt, "unit": "audio-hours/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "strong",
+                "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+                "config": {"workload": f"one {args.hours:g} h 48 kHz stereo f32 stream time-sharded over {world} ranks, shards resident in "
+                                       f"HBM (BASELINE configs[4]); side figure", "bytes_total": frames * ch * 4,
+                           "parallelism": f"time-sharded x{world}" + (" (one-device rehearsal over gloo)" if rehearsal else " over RCCL")},
+                "phase_ms_max_over_ranks": phase_ms, "hbm_gbs_whole_step": frames * ch * 4 / dt / 1e9, "result": res}), flush=True)
+        return
     pcm = torch.empty((frames, ch), dtype=torch.float32, device=dev)
     meter.synth_fill(pcm.data_ptr(), 77, fs, ch, frames)
     torch.cuda.synchronize()
@@ -301,6 +371,63 @@ def run_config5(args, meter, dev, local):
                     "peaks_identical": a["peak_per_ch"] == b["peak_per_ch"]}
     out["config"] = {"workload": f"one {args.hours:g} h 48 kHz stereo f32 stream resident in HBM (BASELINE configs[4]), 1 device; side figure"}
     print(json.dumps(out), flush=True)
+
+
+def run_config3_strong(args, meter, dev, rank, world, rehearsal):
+    """BASELINE configs[2]: ONE batch of 10,000 x 180 s 48 kHz stereo tracks split file-by-file over the ranks
+    (headroom_amd.sharded.partition_tracks_by_bytes: longest first onto the least-loaded rank; no data-path collective,
+    results gathered on the host), strong scaling.  A rank's share is analysed in launches of at most --tracks
+    (default 1250 = 86.4 GB) tracks; when the share exceeds what is resident, the resident tracks are analysed again
+    (the work is done every time; only the synthetic bytes repeat) -- on one GPU the 10,000 tracks are 8 launches."""
+    import torch
+
+    import headroom_amd as hr
+    from headroom_amd import sharded
+    fs, ch = 48000, 2
+    frames = fs * SECONDS
+    total = args.total_tracks or 10000
+    per_launch = args.tracks or 1250
+    mine = sharded.partition_tracks_by_bytes([frames * ch * 4] * total, world)[rank]
+    n_res = min(len(mine), per_launch)
+    if rehearsal:  # every rank on one device: keep the resident pool small
+        n_res = min(n_res, max(1, per_launch // world))
+    pcm = torch.empty((max(n_res, 1), frames, ch), dtype=torch.float32, device=dev)
+    for i in range(n_res):
+        meter.synth_fill(pcm[i].data_ptr(), 3000 + mine[i], fs, ch, frames)
+    torch.cuda.synchronize()
+    launches = []
+    left = len(mine)
+    while left > 0:
+        k = min(left, n_res)
+        launches.append(hr.TrackBatch([hr.TrackSpec(pcm[i].data_ptr(), fs, channels=ch, fmt=hr.FMT_F32, frames=frames) for i in range(k)]))
+        left -= k
+    for _ in range(args.warmup):
+        for b in launches[:1]:
+            meter.analyze_prepared(b)
+    _dist_barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        for b in launches:
+            meter.analyze_prepared(b)
+    _dist_barrier(world)
+    elapsed = _dist_max(time.perf_counter() - t0, world, rehearsal, dev)
+    assert all(st == 0 for b in launches for st in b.statuses())
+    if world > 1:
+        import torch.distributed as dist
+        counts = [None] * world
+        dist.all_gather_object(counts, len(mine))   # the host-side gather of analyze_files: here only the counts
+        assert sum(counts) == total
+    if rank == 0:
+        dt = elapsed / args.steps
+        print(json.dumps({
+            "metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": total * SECONDS / 3600.0 / dt, "unit": "audio-hours/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{total}-track batch of 180 s 48 kHz stereo f32 PCM split per file over {world} ranks (BASELINE "
+                                   f"configs[2]); side figure", "tracks_this_rank": len(mine), "launches_this_rank": len(launches),
+                       "resident_tracks_this_rank": n_res, "bytes_total": total * frames * ch * 4,
+                       "parallelism": f"track-sharded x{world}" + (" (one-device rehearsal over gloo)" if rehearsal else "")},
+            "hbm_gbs_whole_step": total * frames * ch * 4 / dt / 1e9}), flush=True)
 
 
 if __name__ == "__main__":

@@ -119,21 +119,37 @@ def allreduce_partial(dist, partial):
     return out
 
 
-def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels, first_hop=0):
+def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels, first_hop=0, timings=None):
     """One rank's part of a time-sharded stream.  `shard_spec` is this rank's TrackSpec (None for a rank
     with an empty shard); first_hop = index of its first hop in the whole stream (cut // hop length).  Every rank of
-    the group must call this; all get the same result dict."""
+    the group must call this; all get the same result dict.  `timings` (a dict) receives this rank's wall seconds per
+    phase: halo exchange, pass 1, edge exchange, pass 2, all-reduce, finish."""
+    import time
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + (t[-1] - t[-2])
+
     part = HrShardPartial()
     part.range_ok = 1  # a rank that sits the passes out does not veto the range statistics
     if shard_spec is not None and rank < active:
         head = meter.shard_head(shard_spec)
         # pass 1 needs the neighbours' 16-frame halos: tails travel right, heads travel left
         left_tail, right_head = _exchange_halos(dist, meter, shard_spec, head, rank, active)
+        lap("halo_exchange")
         edge = meter.shard_pass1(shard_spec, left_tail, right_head, first_hop)
+        lap("pass1")
         left_edge = exchange_edges(dist, edge, rank, active)
+        lap("edge_exchange")
         part = meter.shard_pass2(left_edge)
+        lap("pass2")
     red = allreduce_partial(dist, part)
-    return meter.shard_finish(red, channels)
+    lap("all_reduce")
+    out = meter.shard_finish(red, channels)
+    lap("finish")
+    return out
 
 
 def _exchange_halos(dist, meter, shard_spec, head, rank, active):
