@@ -198,6 +198,9 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     const std::vector<uint16_t> &atab = bs ? rt->bs_atab : rt->tp_atab;
     rd.swr_phases = phases;
     rd.swr_step = bs ? rt->bs_step : rt->swr_step;
+    rd.swr_S = bs ? 1 : rt->swr_S;
+    rd.swr_frac_scale = bs ? 1u : rt->swr_frac_scale;
+    rd.swr_inv_src_incr = bs ? 1.0 : rt->swr_inv_src_incr;
     rd.swr_l1 = bs ? rt->bs_l1 : rt->swr_l1;
     rd.tp_passthru0 = (!bs && rt->swr_step == 1) ? 1 : 0;  // every input frame is a phase-0 output (integer ratio)
     if (phases > 0) {
@@ -1344,7 +1347,8 @@ try {
             if (v) { out[j].status = v; continue; }
             uint64_t m = t.frames;  // frames at 192 kHz
             if (rt->swr_phases > 0)
-                m = t.frames >= kSwrTaps + 1 ? (t.frames * rt->swr_phases + rt->swr_step - 1) / rt->swr_step : 0;
+                m = t.frames >= kSwrTaps + 1
+                        ? (t.frames * rt->swr_phases * static_cast<uint64_t>(rt->swr_S) + rt->swr_step - 1) / rt->swr_step : 0;
             const size_t bytes = (m * t.channels * sizeof(double) + 255) / 256 * 256;
             if (!pseudo.empty() && need + bytes > limit) break;
             hr_track p = t;
@@ -1387,9 +1391,10 @@ try {
                     ctx->swr_banks.emplace_back(t.sample_rate, bank);
                 }
                 if (rt->swr_phases > 0)
-                    launch_resample_swr(t.fmt, src, t.frames, t.channels, rt->swr_phases, rt->swr_step, bank, dst, st);
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, rt->swr_phases, rt->swr_step, rt->swr_S, rt->swr_frac_scale,
+                                        rt->swr_inv_src_incr, bank, dst, st);
                 else  // 192 kHz input: the resampler passes it through; the f64 copy keeps one code path
-                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, ctx->unit_tap.as<double>(), dst, st);
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, 1, 1u, 1.0, ctx->unit_tap.as<double>(), dst, st);
             }
             if (!rc && hipGetLastError() != hipSuccess) rc = HR_ERR_HIP;
             std::vector<hr_result> res(pseudo.size());

@@ -39,6 +39,10 @@ struct RateDev {
     uint32_t hop;
     int32_t swr_phases, swr_step;
     double swr_l1;
+    // phase-interpolated resampling (RateTables::swr_S > 1: 22.05 kHz, 11.025 kHz, ...): see hr_tables.hpp
+    int32_t swr_S;
+    uint32_t swr_frac_scale;
+    double swr_inv_src_incr;
     // The bank above is libswresample's (HR_TP_SWR192K) or the BS.1770 Annex 2 oversampler in the same shape
     // (HR_TP_BS1770), chosen when the context builds its tables.  tp_passthru0: phase 0 is a unit impulse (swr), so
     // its outputs are the samples themselves and the sample peak is a lower bound of the true peak.

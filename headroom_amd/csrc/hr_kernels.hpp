@@ -34,9 +34,10 @@ void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkIt
                         const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st);
 // hop sums of the stereo planes of a split track -> the track's own (hop, channel) slots; one workgroup per parent
 void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
-// libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases/step) interleaved f64 frames
-void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, const double *taps,
-                         double *dst, hipStream_t st);
+// libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases*S/step) interleaved f64 frames
+// (S, frac_scale, inv_src_incr: RateTables::swr_S / swr_frac_scale / swr_inv_src_incr; 1, 1, 1.0 for exact phase counts)
+void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, int S, uint32_t frac_scale,
+                         double inv_src_incr, const double *taps, double *dst, hipStream_t st);
 // tp_kind: 0 = the context's interpolation bank (libswresample's or BS.1770's, RateDev), 2 = sample peak; every item
 // covers `span` (multiple of 256) positions, or item.pad positions when that is non-zero (bank kernel only)
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,

@@ -655,6 +655,13 @@ __device__ __forceinline__ void peak_commit(double m, unsigned long long *slot)
     if ((threadIdx.x & 63) == 0 && m > 0.0) atomicMax(slot, static_cast<unsigned long long>(__double_as_longlong(m)));
 }
 
+// Resampler bookkeeping (hr_tables.hpp): output n sits at floor(n * D / S) phase units.  First output at or after q
+// phase units: ceil(q * S / D), formed without overflowing 64 bits (q < 2^46, S < 2^30, D < 2^30).
+__device__ __forceinline__ int64_t swr_first_output(int64_t q, int64_t D, int64_t S)
+{
+    return (q / D) * S + ((q % D) * S + D - 1) / D;
+}
+
 // Each workgroup covers `span` consecutive positions starting at item.first (positions past the valid
 // range are skipped), 256 at a time.
 template <int FMT>
@@ -680,15 +687,24 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
             double x[kSwrTaps];
 #pragma unroll
             for (int i = 0; i < kSwrTaps; i++) x[i] = fetch<FMT>(t, c, pos - 15 + i, t.tp_reflect != 0);
-            // outputs n with floor(n*step/P) == pos
-            const int64_t n_lo = (pos * P + step - 1) / step;
-            const int64_t n_hi = ((pos + 1) * P + step - 1) / step;
+            // outputs n with floor(n*step/S) in [pos*P, (pos+1)*P)
+            const int64_t S = r.swr_S;
+            const int64_t n_lo = swr_first_output(pos * P, step, S);
+            const int64_t n_hi = swr_first_output((pos + 1) * P, step, S);
             for (int64_t n = n_lo; n < n_hi; n++) {
-                const int ph = static_cast<int>(n * step - pos * P);
+                const int64_t num = n * step;
+                const int ph = static_cast<int>(num / S - pos * P);
                 const double *__restrict__ f = r.swr_taps + static_cast<size_t>(ph) * kSwrTaps;
                 double val = 0.0;
 #pragma unroll
                 for (int i = 0; i < kSwrTaps; i++) val = fma(x[i], f[i], val);
+                if (S > 1) {  // resample_linear: between this phase and the next, weight frac / src_incr
+                    double v2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < kSwrTaps; i++) v2 = fma(x[i], f[kSwrTaps + i], v2);
+                    const double frac = static_cast<double>(static_cast<uint32_t>(num % S) * r.swr_frac_scale);
+                    val += (v2 - val) * r.swr_inv_src_incr * frac;
+                }
                 const double a = fabs(val);
                 m = a > m ? a : m;
             }
@@ -701,13 +717,14 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
 // defaults, f64; start reflected x[-k] = x[k], and, unlike f_ebur128's private resampler, flushed at the end with
 // the reflection x[N+j] = x[N-1-j]).  One thread per input position writes the outputs n with floor(n*step/P) == pos.
 template <int FMT>
-__global__ void __launch_bounds__(256) k_resample_swr(const void *__restrict__ src, int64_t N, int C, int P, int step,
+__global__ void __launch_bounds__(256) k_resample_swr(const void *__restrict__ src, int64_t N, int C, int P, int step, int S,
+                                                      uint32_t frac_scale, double inv_src_incr,
                                                       const double *__restrict__ taps, double *__restrict__ dst)
 {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
     for (int64_t pos = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; pos < N; pos += stride) {
-        const int64_t n_lo = (pos * P + step - 1) / step;
-        const int64_t n_hi = ((pos + 1) * P + step - 1) / step;
+        const int64_t n_lo = swr_first_output(pos * P, step, S);
+        const int64_t n_hi = swr_first_output((pos + 1) * P, step, S);
         for (int c = 0; c < C; c++) {
             double x[kSwrTaps];
 #pragma unroll
@@ -718,24 +735,31 @@ __global__ void __launch_bounds__(256) k_resample_swr(const void *__restrict__ s
                 x[i] = (k < 0 || k >= N) ? 0.0 : ld_sample<FMT>(src, static_cast<uint64_t>(k) * C + c);
             }
             for (int64_t n = n_lo; n < n_hi; n++) {
-                const int ph = static_cast<int>(n * step - pos * P);
+                const int64_t num = n * step;
+                const int ph = static_cast<int>(num / S - pos * P);
                 const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
                 double val = 0.0;
 #pragma unroll
                 for (int i = 0; i < kSwrTaps; i++) val = fma(x[i], f[i], val);
+                if (S > 1) {  // (as in k_true_peak_swr)
+                    double v2 = 0.0;
+#pragma unroll
+                    for (int i = 0; i < kSwrTaps; i++) v2 = fma(x[i], f[kSwrTaps + i], v2);
+                    val += (v2 - val) * inv_src_incr * static_cast<double>(static_cast<uint32_t>(num % S) * frac_scale);
+                }
                 dst[n * C + c] = val;
             }
         }
     }
 }
 
-void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, const double *taps,
-                         double *dst, hipStream_t st)
+void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, int S, uint32_t frac_scale,
+                         double inv_src_incr, const double *taps, double *dst, hipStream_t st)
 {
     if (!frames) return;
     uint64_t blocks = (frames + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-#define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, taps, dst); break;
+#define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, S, frac_scale, inv_src_incr, taps, dst); break;
     switch (fmt) { HR_RS_CASE(0) HR_RS_CASE(1) HR_RS_CASE(2) HR_RS_CASE(3) default: HR_RS_CASE(4) }
 #undef HR_RS_CASE
 }

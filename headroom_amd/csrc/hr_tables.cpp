@@ -88,10 +88,20 @@ static void build_swr(RateTables &rt)
     const uint32_t out_rate = 192000;
     if (rt.fs >= out_rate) return;
     const uint64_t g = gcd_u64(rt.fs, out_rate);
-    const int P = static_cast<int>(out_rate / g);
-    if (P > 1024) { rt.swr_phases = -1; return; }  // libswresample would interpolate between phases
+    // resample_init: exact_rational takes out/gcd phases when that fits 1 << phase_shift = 1024; else 1024 phases and
+    // linear interpolation between them.  dst_incr / src_incr = in * phases / out in lowest terms (av_reduce), both
+    // doubled until one reaches 1 << 20.
+    const int P = out_rate / g <= 1024 ? static_cast<int>(out_rate / g) : 1024;
+    const uint64_t den = static_cast<uint64_t>(rt.fs) * P, g2 = gcd_u64(out_rate, den);
+    uint64_t src_incr = out_rate / g2, dst_incr = den / g2;
+    if (src_incr > 0x3fffffffu || dst_incr > 0x3fffffffu) { rt.swr_phases = -1; return; }  // av_reduce would approximate
     rt.swr_phases = P;
-    rt.swr_step = static_cast<int>(rt.fs / g);
+    rt.swr_step = static_cast<int>(dst_incr);
+    rt.swr_S = static_cast<int>(src_incr);
+    uint32_t scale = 1;
+    while (dst_incr < (1u << 20) && src_incr < (1u << 20)) { dst_incr *= 2; src_incr *= 2; scale *= 2; }
+    rt.swr_frac_scale = scale;
+    rt.swr_inv_src_incr = 1.0 / static_cast<double>(src_incr);
     rt.swr_taps.assign(static_cast<size_t>(P + 1) * kSwrTaps, 0.0);
     const int center = (kSwrTaps - 1) / 2;
     const int ph_nb = P % 2 ? P : P / 2 + 1;
@@ -113,8 +123,9 @@ static void build_swr(RateTables &rt)
         for (int i = 0; i < kSwrTaps; i++)
             taps[(P - ph) * kSwrTaps + kSwrTaps - 1 - i] = taps[ph * kSwrTaps + i];
     }
-    if (P % 2)
-        for (int i = 0; i < kSwrTaps; i++) taps[P * kSwrTaps + i] = i ? taps[i - 1] : 0.0;
+    // entry P = phase 0 delayed by one sample (resample_init's two memcpy's; the same as the mirror image written above
+    // when P is even)
+    for (int i = 0; i < kSwrTaps; i++) taps[P * kSwrTaps + i] = i ? taps[i - 1] : taps[kSwrTaps - 1];
     for (int ph = 0; ph < P; ph++) {
         double l1 = 0;
         for (int i = 0; i < kSwrTaps; i++) l1 += std::fabs(taps[ph * kSwrTaps + i]);
@@ -311,7 +322,9 @@ const RateTables *rate_tables(uint32_t fs)
     build_swr(*rt);
     // (the sample peak stands in for phase 0 only where EVERY input frame is a phase-0 output, i.e. at integer ratios:
     // at 44.1 kHz only every 147th frame is one, and an isolated peak between two of them is not an output at all)
-    build_tp_tiles(rt->swr_phases, rt->swr_step, rt->swr_taps, rt->swr_step == 1, rt->tp_atab, rt->tp_np, rt->tp_mt, rt->tp_max_out);
+    // (phase-interpolated rates -- swr_S > 1 -- have no tile table: their true peak runs on the generic kernel)
+    if (rt->swr_S == 1)
+        build_tp_tiles(rt->swr_phases, rt->swr_step, rt->swr_taps, rt->swr_step == 1, rt->tp_atab, rt->tp_np, rt->tp_mt, rt->tp_max_out);
     build_bs1770(*rt);
     build_tp_tiles(rt->bs_phases, rt->bs_step, rt->bs_taps, false, rt->bs_atab, rt->bs_np, rt->bs_mt, rt->bs_max_out);
     const RateTables *p = rt.get();

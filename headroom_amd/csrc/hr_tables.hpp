@@ -39,7 +39,14 @@ struct RateTables {
     double q_ab[2][2] = {{0, 0}, {0, 0}};
     double q_residual = 0;
     // libswresample bank to 192 kHz (phase_count == 0: no resampling, true peak = sample peak)
+    // Output n of the resampler sits at idx = floor(n * swr_step / swr_S) phase units: input position idx / swr_phases, phase
+    // idx % swr_phases.  Exact phase counts (out/gcd <= 1024): swr_S == 1.  Otherwise (22.05 kHz, 11.025 kHz, ...) libswresample
+    // keeps 1024 phases and interpolates linearly between neighbouring phases with weight frac / src_incr, frac =
+    // ((n * swr_step) % swr_S) * swr_frac_scale, 1 / src_incr = swr_inv_src_incr (resample_init / resample_linear).
     int swr_phases = 0, swr_step = 0;
+    int swr_S = 1;
+    uint32_t swr_frac_scale = 1;
+    double swr_inv_src_incr = 1.0;
     std::vector<double> swr_taps;  // [(phases+1)][32]
     double swr_l1 = 0;             // max over phases of sum |tap|
     // f16 coefficient tiles of the MFMA true-peak screen (hr_kernels_fused.hip): one tile of 16 input

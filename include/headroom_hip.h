@@ -45,6 +45,12 @@ enum {
     HR_GATE_LOUDNORM = 2  /* libavfilter/ebur128.c (af_loudnorm): 1000 x 0.1 LU histogram     */
 };
 
+/* Known divergence from f_ebur128 at sample rates that are not a multiple of 10 Hz (11 025 Hz; none of the usual
+ * rates otherwise): FFmpeg ticks every fs/10 samples but its 400 ms / 3 s rings hold fs*4/10 / fs*3 samples, i.e. four
+ * hops plus fs*4/10 - 4*(fs/10) <= 3 samples, and its first block appears one tick later.  The meter takes a block as
+ * exactly four hops (normalised by fs*4/10): one block more, each block 2 samples of 4410 short at 11 025 Hz (< 0.005 LU
+ * on steady material).  tests/test_oracle_kat.py::test_block_count_at_rates_not_divisible_by_ten pins this. */
+
 /* true peak: which interpolator */
 enum {
     HR_TP_SWR192K = 0, /* libswresample defaults to 192 kHz, as f_ebur128 peak=true (default) */

@@ -489,14 +489,42 @@ static uint64_t gcd_u64(uint64_t a, uint64_t b)
     return a;
 }
 
-int hro_swr_bank(uint32_t in_rate, uint32_t out_rate, int *in_step, double *taps)
+static double tp_src(const hro_track *t, int c, int64_t i);
+
+/* resample_init(): phase count, and the dst_incr / src_incr bookkeeping of the resampling loop.  exact_rational: the
+ * phase count is out/gcd(in, out) when that is <= 1 << phase_shift (1024); else it stays 1024 and the loop
+ * interpolates linearly between neighbouring phases (linear_interp = 1: resample_linear is taken whenever frac or
+ * dst_incr_mod is non-zero, swri_resample()).  src_incr / dst_incr = av_reduce(out, in * phase_count), both doubled
+ * until one reaches 1 << 20.  Output n sits at idx = floor(n * dst_incr / src_incr) phase units (input position
+ * idx / phase_count, phase idx % phase_count) with frac = (n * dst_incr) % src_incr. */
+int hro_swr_plan(uint32_t in_rate, uint32_t out_rate, hro_swr_plan_t *pl)
 {
+    memset(pl, 0, sizeof *pl);
     if (!in_rate || !out_rate || in_rate >= out_rate) return 0; /* no upsampling needed / unsupported */
     const uint64_t g = gcd_u64(in_rate, out_rate);
-    const int phase_count = (int)(out_rate / g); /* exact_rational */
-    const int step = (int)(in_rate / g);
-    if (phase_count > 1024) return 0; /* would fall back to 1024 phases + linear interpolation */
-    if (in_step) *in_step = step;
+    uint64_t phase_count = 1024;
+    if (out_rate / g <= 1024) phase_count = out_rate / g;
+    const uint64_t den = (uint64_t)in_rate * phase_count;
+    const uint64_t g2 = gcd_u64(out_rate, den);
+    uint64_t src_incr = out_rate / g2, dst_incr = den / g2;
+    if (src_incr > 0x3fffffffu || dst_incr > 0x3fffffffu) return 0; /* av_reduce would approximate: not restated */
+    pl->phases = (int)phase_count;
+    pl->d0 = (uint32_t)dst_incr;
+    pl->s0 = (uint32_t)src_incr;
+    uint32_t scale = 1;
+    while (dst_incr < (1u << 20) && src_incr < (1u << 20)) { dst_incr *= 2; src_incr *= 2; scale *= 2; }
+    pl->frac_scale = scale;
+    pl->inv_src_incr = 1.0 / (double)src_incr;
+    pl->linear = (dst_incr % src_incr) != 0;
+    return pl->phases;
+}
+
+int hro_swr_bank(uint32_t in_rate, uint32_t out_rate, int *in_step, double *taps)
+{
+    hro_swr_plan_t pl;
+    const int phase_count = hro_swr_plan(in_rate, out_rate, &pl);
+    if (!phase_count) return 0;
+    if (in_step) *in_step = (int)pl.d0; /* exact phase counts: s0 == 1 and d0 is the input step per output in phases */
     if (!taps) return phase_count;
 
     const int tap_count = HRO_SWR_TAPS;
@@ -525,11 +553,33 @@ int hro_swr_bank(uint32_t in_rate, uint32_t out_rate, int *in_step, double *taps
         for (int i = 0; i < tap_count; i++)
             taps[(phase_count - ph) * tap_count + tap_count - 1 - i] = taps[ph * tap_count + i];
     }
-    if (phase_count % 2) { /* entry phase_count = phase 0 delayed by one sample */
-        for (int i = 0; i < tap_count; i++)
-            taps[phase_count * tap_count + i] = i ? taps[i - 1] : 0.0;
-    }
+    /* entry phase_count = phase 0 delayed by one sample (resample_init's two memcpy's; for an even phase count the
+     * mirror image of phase 0 written above is the same thing) */
+    for (int i = 0; i < tap_count; i++)
+        taps[phase_count * tap_count + i] = i ? taps[i - 1] : taps[tap_count - 1];
     return phase_count;
+}
+
+/* One output of the resampling loop (resample_common / resample_linear of resample_template.c, DBL): n-th output of
+ * channel c.  *pos_out receives its input position floor(t). */
+static double swr_output(const hro_track *t, const hro_swr_plan_t *pl, const double *taps, int c, uint64_t n, int64_t *pos_out)
+{
+    const uint64_t num = n * pl->d0; /* n < 2^40, d0 < 2^30 would overflow: callers keep n * d0 < 2^63 (hours of audio do) */
+    const uint64_t idx = num / pl->s0;
+    const uint32_t frac = (uint32_t)(num % pl->s0) * pl->frac_scale;
+    const int64_t pos = (int64_t)(idx / (uint64_t)pl->phases);
+    const int ph = (int)(idx % (uint64_t)pl->phases);
+    const double *f = taps + (size_t)ph * HRO_SWR_TAPS;
+    double val = 0.0;
+    for (int i = 0; i < HRO_SWR_TAPS; i++) val = fma(tp_src(t, c, pos - 15 + i), f[i], val);
+    if (pl->linear) {
+        const double *f2 = f + HRO_SWR_TAPS;
+        double v2 = 0.0;
+        for (int i = 0; i < HRO_SWR_TAPS; i++) v2 = fma(tp_src(t, c, pos - 15 + i), f2[i], v2);
+        val += (v2 - val) * pl->inv_src_incr * frac;
+    }
+    if (pos_out) *pos_out = pos;
+    return val;
 }
 
 static const double bs1770_taps[4][12] = {
@@ -565,7 +615,8 @@ static void true_peak_swr(const hro_track *t, int flush_end, double *peak)
     int step = 0;
     const int C = t->channels;
     const int64_t N = (int64_t)t->frames;
-    const int P = hro_swr_bank(t->sample_rate, 192000, &step, NULL);
+    hro_swr_plan_t pl;
+    const int P = hro_swr_plan(t->sample_rate, 192000, &pl);
     for (int c = 0; c < C; c++) peak[c] = 0.0;
     if (P == 0) { /* 192 kHz input (no resampling) or unsupported: sample peak */
         for (int c = 0; c < C; c++)
@@ -582,16 +633,12 @@ static void true_peak_swr(const hro_track *t, int flush_end, double *peak)
     const int64_t last_pos = flush_end ? N - 1 : N - 17;
     for (int c = 0; c < C; c++) {
         double pk = 0.0;
-        int64_t pos = 0;
-        int ph = 0;
-        while (pos <= last_pos) {
-            const double *f = taps + (size_t)ph * HRO_SWR_TAPS;
-            double val = 0.0;
-            for (int i = 0; i < HRO_SWR_TAPS; i++) val = fma(tp_src(t, c, pos - 15 + i), f[i], val);
+        for (uint64_t n = 0;; n++) {
+            int64_t pos;
+            const double val = swr_output(t, &pl, taps, c, n, &pos);
+            if (pos > last_pos) break;
             const double a = fabs(val);
             if (a > pk) pk = a;
-            ph += step;
-            while (ph >= P) { ph -= P; pos++; }
         }
         peak[c] = pk;
     }
@@ -774,7 +821,8 @@ int hro_loudnorm_measure(const hro_track *t, hro_result *r)
     if (C < 1 || C > HRO_MAX_CH) return -1;
     const int64_t N = (int64_t)t->frames;
     int step = 0;
-    const int P = hro_swr_bank(t->sample_rate, 192000, &step, NULL);
+    hro_swr_plan_t pl;
+    const int P = hro_swr_plan(t->sample_rate, 192000, &pl);
     const uint32_t rate = P ? 192000u : t->sample_rate;
 
     /* 1. resample every channel to 192 kHz (planar f64) */
@@ -783,20 +831,11 @@ int hro_loudnorm_measure(const hro_track *t, hro_result *r)
     if (P && N >= HRO_SWR_TAPS + 1) {
         double *taps = (double *)malloc((size_t)(P + 1) * HRO_SWR_TAPS * sizeof(double));
         hro_swr_bank(t->sample_rate, 192000, &step, taps);
-        M = ((uint64_t)N * P + step - 1) / step; /* outputs with floor(pos) <= N-1 */
+        /* outputs with floor(pos) <= N-1: n * d0 / s0 < N * P */
+        M = ((uint64_t)N * P * pl.s0 + pl.d0 - 1) / pl.d0;
         res = (double *)malloc((size_t)M * C * sizeof(double));
-        for (int c = 0; c < C; c++) {
-            int64_t pos = 0;
-            int ph = 0;
-            for (uint64_t m = 0; m < M; m++) {
-                const double *f = taps + (size_t)ph * HRO_SWR_TAPS;
-                double val = 0.0;
-                for (int i = 0; i < HRO_SWR_TAPS; i++) val = fma(tp_src(t, c, pos - 15 + i), f[i], val);
-                res[(size_t)c * M + m] = val;
-                ph += step;
-                while (ph >= P) { ph -= P; pos++; }
-            }
-        }
+        for (int c = 0; c < C; c++)
+            for (uint64_t m = 0; m < M; m++) res[(size_t)c * M + m] = swr_output(t, &pl, taps, c, m, NULL);
         free(taps);
     } else if (!P) {
         M = (uint64_t)N;

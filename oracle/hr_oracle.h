@@ -121,6 +121,15 @@ void hro_range_stats(const double *H, uint64_t n_hops, int channels, const float
 /* libswresample filter bank (filter_size 32, kaiser beta 9, exact_rational): returns phase_count
  * (0 if the rate pair is unsupported or needs no resampling) and the per-output input step
  * (dst_incr_div); taps must hold (phase_count+1)*32 doubles when not NULL. */
+/* libswresample/resample.c resample_init(): what the resampling loop needs besides the bank */
+typedef struct hro_swr_plan_t {
+    int phases;           /* filter phases per input sample: out/gcd(in,out) when <= 1024 (exact_rational), else 1024 */
+    int linear;           /* the loop interpolates between neighbouring phases (dst_incr % src_incr != 0) */
+    uint32_t d0, s0;      /* dst_incr / src_incr in lowest terms: output n sits at floor(n*d0/s0) phase units */
+    uint32_t frac_scale;  /* both are doubled until one reaches 1 << 20: frac = ((n*d0) % s0) * frac_scale */
+    double inv_src_incr;  /* 1.0 / (s0 * frac_scale), as resample_linear computes it */
+} hro_swr_plan_t;
+int hro_swr_plan(uint32_t in_rate, uint32_t out_rate, hro_swr_plan_t *plan);
 int hro_swr_bank(uint32_t in_rate, uint32_t out_rate, int *in_step, double *taps);
 
 /* BS.1770-4 Annex 2 coefficients: 4 phases x 12 taps. */

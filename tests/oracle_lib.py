@@ -229,6 +229,21 @@ def loudnorm_measure(pcm, fs, **kw):
     return result_dict(r, t.channels)
 
 
+class SwrPlan(C.Structure):
+    _fields_ = [("phases", C.c_int), ("linear", C.c_int), ("d0", C.c_uint32), ("s0", C.c_uint32), ("frac_scale", C.c_uint32),
+                ("inv_src_incr", C.c_double)]
+
+
+def swr_plan(in_rate, out_rate=192000):
+    """hro_swr_plan: libswresample's phase count and dst_incr / src_incr bookkeeping for this rate pair."""
+    pl = SwrPlan()
+    L = lib()
+    L.hro_swr_plan.argtypes = [C.c_uint32, C.c_uint32, C.POINTER(SwrPlan)]
+    L.hro_swr_plan.restype = C.c_int
+    L.hro_swr_plan(in_rate, out_rate, C.byref(pl))
+    return {f: getattr(pl, f) for f, _ in SwrPlan._fields_}
+
+
 def synth_track(seed, fs, channels, frames):
     out = np.zeros((frames, channels), dtype=np.float32)
     lib().hro_synth_track(seed, fs, channels, frames, out.ctypes.data_as(C.POINTER(C.c_float)))

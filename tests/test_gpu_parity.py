@@ -188,7 +188,7 @@ def test_batch_order_errors_and_device_pcm(oracle, meters):
     b = signals.seeded_noise(32, fs * 2 + 9, 2, -25.0)
     c = signals.seeded_noise(33, 48000 * 2, 1, -6.0)
     td = torch.from_numpy(b).cuda()
-    specs = [hr.TrackSpec(a, fs), hr.TrackSpec(a, 22050),  # 22.05 kHz would need swr's phase interpolation
+    specs = [hr.TrackSpec(a, fs), hr.TrackSpec(a, 768001),  # beyond HR_MAX_SAMPLE_RATE
              hr.TrackSpec(td, fs), hr.TrackSpec(c, 48000), hr.TrackSpec(a, fs)]
     bad = hr.TrackSpec(a, fs)
     bad.c.channels = 9
@@ -580,10 +580,25 @@ def test_other_sample_rates(oracle, meters, fs, tp):
     check_against_oracle(oracle, meters("ebur128", tp), signals.to_s16(x5), fs, "ebur128", tp)
 
 
-def test_bs1770_mode_accepts_rates_libswresample_mode_rejects(oracle, meters):
-    pcm = signals.seeded_noise(77, 22050 * 3, 2, -9.0)
-    check_against_oracle(oracle, meters("ebur128", "bs1770"), pcm, 22050, "ebur128", "bs1770")
-    assert meters().analyze(pcm, 22050)["status"] == hr.ERR_RATE      # 1280 phases: swr would interpolate between phases
+@pytest.mark.parametrize("fs", [22050, 11025, 12345, 64000])
+def test_rates_that_libswresample_interpolates_between_phases(oracle, meters, fs):
+    """22.05 kHz needs 1280 exact phases, 11.025 kHz 2560, 12.345 kHz 128000: more than libswresample's 1024, so it keeps
+    1024 phases and interpolates linearly between neighbours (resample_linear).  The reference hands every file to ffmpeg
+    whatever its rate (src/analyzer.rs:253-265); so does the meter now (generic true-peak kernel; 64 kHz = 3 exact phases
+    rides along as the control).  Peaks bit-identical to the oracle's restatement, both entry points."""
+    pcm = signals.seeded_noise(77 + fs, fs * 3 + 17, 2, -9.0)
+    pcm[fs // 2: fs // 2 + 40] *= 3.0                      # a passage whose true peak sits between the samples
+    for gate in ("ebur128", "loudnorm"):
+        got, ref = check_against_oracle(oracle, meters(gate), pcm, fs, gate)
+        assert got["true_peak_dbtp"] > 20 * math.log10(np.abs(pcm).max()) - 1e-9
+    check_against_oracle(oracle, meters("ebur128", "bs1770"), pcm, fs, "ebur128", "bs1770")
+    x3 = signals.to_s16(signals.seeded_noise(78 + fs, fs * 2 + 5, 3, -15.0))
+    check_against_oracle(oracle, meters(), x3, fs)
+    # the literal first pass of af_loudnorm (resample to 192 kHz, then measure) at the same rate
+    g = meters().loudnorm_first_pass([hr.TrackSpec(pcm, fs)])[0]
+    ref = oracle.loudnorm_measure(pcm, fs)
+    assert g["status"] == 0 and g["peak_per_ch"] == ref["peak_per_ch"]
+    assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
 
 
 @pytest.mark.parametrize("engine", [0, 1])

@@ -135,6 +135,33 @@ def test_swr_bank_interpolates_a_bandlimited_sine(oracle):
         assert abs(y - ref) < 2e-4
 
 
+def test_phase_interpolated_rates_plan_and_known_answers(oracle):
+    """22.05 / 11.025 kHz -> 192 kHz: 1280 / 2560 exact phases exceed libswresample's 1024, so it keeps 1024 phases and
+    interpolates linearly between neighbours.  resample_init's bookkeeping by hand: 192000 / (22050 * 1024) = 5 / 588,
+    doubled 11 times (588 * 2^11 >= 2^20): src_incr 10240, dst_incr 1204224 = 117 * 10240 + 6144."""
+    pl = oracle.swr_plan(22050)
+    assert (pl["phases"], pl["linear"], pl["d0"], pl["s0"], pl["frac_scale"]) == (1024, 1, 588, 5, 2048)
+    assert pl["inv_src_incr"] == 1.0 / 10240
+    pl = oracle.swr_plan(11025)
+    assert (pl["phases"], pl["linear"], pl["d0"], pl["s0"], pl["frac_scale"]) == (1024, 1, 294, 5, 4096)
+    assert oracle.swr_plan(44100)["phases"] == 640 and oracle.swr_plan(44100)["linear"] == 0 and oracle.swr_plan(44100)["d0"] == 147
+    assert oracle.swr_plan(48000)["phases"] == 4 and oracle.swr_plan(96000)["phases"] == 2
+    for fs in (22050, 11025):
+        # EBU 3341 style: fs/4 at 45 degrees has samples +-A/sqrt(2) only, true peak A (tolerance +0.2 / -0.4 dB)
+        n = np.arange(fs * 2)
+        x = 0.5 * np.sin(2 * np.pi * (fs / 4.0) * n / fs + np.pi / 4)
+        pcm = signals.stereo(signals.fade(x, fs // 10))
+        tp = oracle.true_peak(pcm, fs, oracle.TP_SWR192K)
+        assert abs(float(np.abs(pcm).max()) - 0.5 / math.sqrt(2)) < 1e-6
+        assert -0.4 < 20 * math.log10(tp[0] / 0.5) < 0.2, tp
+        # a band-limited sine resampled through the whole path lands on the analytic sine at the 192 kHz instants:
+        # the maximum over a long stretch is the amplitude, to the interpolator's accuracy
+        f0 = fs * 0.11
+        y = signals.stereo(signals.fade(0.25 * np.sin(2 * np.pi * f0 * n / fs + 0.3), fs // 4))  # (no edges: they ring)
+        tp = oracle.true_peak(y, fs, oracle.TP_SWR192K)
+        assert abs(tp[0] / 0.25 - 1.0) < 5e-4, tp
+
+
 def test_silence_and_short_input(oracle):
     z = np.zeros((48000 * 2, 2), dtype=np.float32)
     r = oracle.measure(z, 48000)
@@ -166,6 +193,26 @@ def test_block_count_and_hop_identity(oracle):
         assert r["n_gated"] == lit["n_gated"]
         assert abs(r["integrated_lufs"] - lit["integrated_lufs"]) < 1e-9
         assert abs(r["rel_threshold_lufs"] - lit["rel_threshold_lufs"]) < 1e-9
+
+
+def test_block_count_at_rates_not_divisible_by_ten(oracle):
+    """Documented divergence (include/headroom_hip.h): at fs % 10 != 0 (11 025 Hz) f_ebur128 ticks every
+    fs / 10 = 1102 samples but keeps a ring of fs * 4 / 10 = 4410 samples, so its windows are four hops PLUS two samples and
+    its first block appears at the fifth tick: floor(N / 1102) - 4 blocks.  The meter and the oracle take a block as four
+    hops (4408 samples, normalised by 4410) from the fourth tick on: floor(N / 1102) - 3 blocks.  This test pins what is
+    implemented, so that a later change to the ring form is a visible decision."""
+    fs = 11025
+    pcm = signals.seeded_noise(5, fs * 6 + 77, 2, -20.0)
+    r = oracle.measure(pcm, fs, tp_mode=oracle.TP_SAMPLE)
+    ticks = pcm.shape[0] // (fs // 10)
+    assert fs // 10 == 1102 and fs * 4 // 10 == 4410
+    assert r["n_blocks"] == ticks - 3          # f_ebur128 itself: ticks - 4
+    # steady noise: the two samples per window that the simplification leaves out move the loudness by < 0.005 LU
+    lit = 10 * math.log10(4408 / 4410)
+    assert abs(lit) < 0.005
+    # rates divisible by ten (every rate of BASELINE.json's configs) have no such difference
+    for ok in (8000, 22050, 44100, 48000, 88200, 96000, 176400, 192000):
+        assert ok * 4 // 10 == 4 * (ok // 10)
 
 
 def test_gating_modes_agree_closely(oracle):
