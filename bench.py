@@ -77,6 +77,10 @@ def main():
                          "(1,250 tracks, 86.4 GB; a side figure); config4 = 96 kHz 24-bit 5.1 tracks (a side figure: split into "
                          "stereo f32 planes on the device, then the same fused kernel); config5 = one 10-hour 48 kHz stereo stream, "
                          "whole and as 8 time shards on this one device (a side figure)")
+    ap.add_argument("--seconds", type=float, default=180.0,
+                    help="track length of the config2 / config3 batch (180 = the BASELINE workload; e.g. --seconds 10 --tracks 10000 is the "
+                         "short-clip side figure: per-track fixed costs -- the last hop and the ragged tail -- weigh 18 times more)")
+    ap.add_argument("--ragged", type=int, default=0, help="extra frames per track beyond a whole number of hops (side figures)")
     ap.add_argument("--hours", type=float, default=10.0, help="config5: length of the stream")
     ap.add_argument("--total-tracks", type=int, default=0,
                     help="config3 with --gpus N > 1 (or this flag): the whole batch is this many tracks (default 10000 = BASELINE "
@@ -109,9 +113,10 @@ def main():
         torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    global FS
+    global FS, SECONDS
     if args.workload == "config3":
         FS = 48000
+    SECONDS = args.seconds if args.seconds != int(args.seconds) else int(args.seconds)
     n_tracks = args.tracks or (1250 if args.workload == "config3" else 1000)
     meter = hr.Meter(device=local, engine=args.engine, tp_mode={"swr192k": 0, "bs1770": 1, "sample": 2}[args.tp_mode])
     if args.workload == "config4":
@@ -130,7 +135,7 @@ def main():
         if world > 1:
             dist.destroy_process_group()
         return
-    frames = FS * SECONDS
+    frames = int(FS * SECONDS) + args.ragged
     # HR_BENCH_OFFSET (experiments): byte offset of every track inside its slot, to see what cache-line alignment is worth
     boff = int(os.environ.get("HR_BENCH_OFFSET", "0"))
     pcm = torch.empty((n_tracks, frames + (16 if boff else 0), CH), dtype=torch.float32, device=dev)
@@ -190,7 +195,7 @@ def main():
         # committed measurement (profiles/r1_fused_hbm_traffic.json, bytes per track) scaled to this launch
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_fused_hbm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32":
+        if os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32" and SECONDS == 180 and not args.ragged:
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_track"] * n_tracks
             traffic_src = "profiles/r1_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
@@ -199,7 +204,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{n_tracks}-track batch per GPU of 180 s {FS / 1000:g} kHz stereo {args.pcm_format} PCM resident in HBM "
+            "config": {"workload": f"{n_tracks}-track batch per GPU of {SECONDS:g} s {FS / 1000:g} kHz stereo {args.pcm_format} PCM resident in HBM "
                                    f"(BASELINE configs[{2 if args.workload == 'config3' else 1}]); per-track integrated LUFS (ebur128 gating) + dBTP ({'192 kHz' if args.tp_mode == 'swr192k' else args.tp_mode})",
                        "tracks_per_gpu": n_tracks, "bytes_per_gpu": bytes_per_step, "parallelism": f"track-sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -209,7 +214,8 @@ def main():
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
-        if world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2" and args.tp_mode == "swr192k":
+        if (world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2" and args.tp_mode == "swr192k"
+                and SECONDS == 180 and not args.ragged):
             # one thread per core of the job's CPU share: the scheduler's affinity mask when it is narrower than the
             # machine, else the box's documented share of 16 cores per GPU
             try:

@@ -107,7 +107,7 @@ struct hr_ctx {
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
     std::vector<FusedItem> h_fitems;
-    std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
+    std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel (2: the final hop too)
     std::vector<WorkItem> h_ovf_items, h_gate_items;
     bool no_s16_direct = false;  // HR_NO_S16_DIRECT=1: stereo s16 is widened into f32 planes first, as before
     // the next three are set only by the experiments library (-DHR_EXPERIMENTS, make exp); always false / 0 in the shipped one
@@ -318,6 +318,19 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         const bool plain = ctx->cfg.tp_mode == HR_TP_SAMPLE || ctx->rates_h[d.rate_idx].swr_phases == 0;
         fsp[i] = ok && do_peaks && !ftp[i] && plain;
     }
+    // The track's final hop joins the fused rows (instead of the generic one-lane-per-hop kernel) when the stream ends
+    // with this track and the fused kernel can keep the row honest (hr_kernels_fused.hip, "FINAL hop"): either the ragged
+    // tail is long enough that every byte the row touches exists (22 frames: the row reads 16*(T+1) - hop <= 22 frames
+    // past the hop), or the row's 16-byte chunks are 16-byte aligned, so that a chunk that STARTS inside the track never
+    // crosses a page behind its end.
+    std::vector<uint8_t> ffin(nt, 0);
+    for (size_t i = 0; i < nt; i++) {
+        const TrackDesc &d = g.descs[i];
+        if (!fkw[i] || !d.stream_end || d.right_head || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
+        const uint64_t ragged = d.frames - d.n_hops * d.hop;
+        const uint64_t row_bytes = static_cast<uint64_t>(d.hop) * fmt_bytes(d.fmt) * 2;
+        ffin[i] = ragged >= 22 || row_bytes % 16 == 0;
+    }
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
@@ -335,7 +348,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                 const RateDev &rd = ctx->rates_h[ri];
                 const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
-                const uint64_t interior = g.descs[i].n_hops - 1;
+                const uint64_t interior = g.descs[i].n_hops - (ffin[i] ? 0 : 1);
                 for (uint64_t h = 0; h < interior; h += 64)
                     fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
             }
@@ -373,7 +386,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     for (int f = 0; f < 3; f++) {
         tail_span[f].off = items.size();
         for (size_t i = 0; i < nt; i++)
-            if (fkw[i] && g.fmts[i] == f)
+            if (fkw[i] && !ffin[i] && g.fmts[i] == f)
                 for (uint32_t c = 0; c < g.descs[i].ch; c++) items.push_back({static_cast<uint32_t>(i), c, g.descs[i].n_hops - 1});
         tail_span[f].n = items.size() - tail_span[f].off;
     }
@@ -395,7 +408,10 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     if (g.fmts[i] != f || g.descs[i].role == 1) continue;
                     const bool plain = ctx->cfg.tp_mode != HR_TP_SAMPLE && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0;
                     if (plain != (kind == 1)) continue;
-                    const uint64_t n0 = (ftp[i] || fsp[i]) ? (g.descs[i].n_hops - 1) * g.descs[i].hop : 0;
+                    // fused tracks: the generic kernel finishes the track -- from the last hop on, or, when the final hop
+                    // is a fused row too, from the first position of its tile T-2 (the last two tiles are not screened there)
+                    const uint64_t last_hop0 = (g.descs[i].n_hops - 1) * g.descs[i].hop;
+                    const uint64_t n0 = !(ftp[i] || fsp[i]) ? 0 : !ffin[i] ? last_hop0 : last_hop0 + 16ull * ((g.descs[i].hop + 15) / 16 - 2);
                     // (the tail of a fused track is cut into short items: many brief workgroups beside the fused kernel
                     // instead of one long-running one)
                     const uint32_t span = ftp[i] && kind == 0 ? kTailSpan : 0;
@@ -424,6 +440,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
     }
     ctx->h_ftp.assign(ftp.begin(), ftp.end());
+    for (size_t i = 0; i < nt; i++)
+        if (ftp[i] && ffin[i]) ctx->h_ftp[i] = 2;  // (the fused rows reach into the final hop: redo_overflowed_peaks)
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
@@ -588,7 +606,9 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     for (int f = 0; f < 3; f++) {
         for (size_t i = 0; i < nt; i++) {
             if (!ctx->h_ftp[i] || !ovf[i] || g.fmts[i] != f) continue;
-            const uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
+            // everything the fused kernel screened: up to the last hop, or (final hop fused too) up to its tile T-2
+            uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
+            if (ctx->h_ftp[i] == 2) end += 16ull * ((g.descs[i].hop + 15) / 16 - 2);
             for (uint64_t n = 0; n < end; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
         }
         fmt_end[f] = items.size();

@@ -361,6 +361,22 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const unsigned rd_swz = INF == 2 ? (lane >> 3) & 1 : INF == 1 ? (lane >> 2) & 3 : (lane >> 1) & 7;  // s24: a rotation, not an xor
     const char *my_lds = lbuf + lane * PB;
 
+    // ---- the track's FINAL hop as a row (the host puts it here when the stream ends with this track and, see
+    // run_measure, the row's pieces are 16-byte aligned or the ragged tail is long enough).  Its pieces T-1 and T reach
+    // past the hop, possibly past the track: frames at or beyond fin_valid (frames from the row's start to the track's end)
+    // do not exist.  Three things keep the row honest, all behind wave-uniform branches in the last three steps:
+    //   * DMA lanes whose 16-byte chunk starts at or beyond the track's end are switched off (their LDS slots keep stale bytes);
+    //   * frames >= fin_valid are zeroed as they leave LDS (they never reach the sample peak or the f16 fragments);
+    //   * the tiles T-2 and T-1, whose windows reach into those frames, are not screened for this row: their positions
+    //     (and the ragged tail) stay with the bounds-checked generic kernel, which the host starts at position 16*(T-2).
+    // (a padding item, n_rows == 0, works on row 0 of the item it copies: when that is a one-row wave holding a final
+    // hop, the padding wave needs the same care -- it reads the same bytes)
+    const bool fin_wave = it.first_hop + static_cast<uint64_t>(last_row + 1) == t.n_hops;
+    const long long fin_left = static_cast<long long>(t.frames) - static_cast<long long>((it.first_hop + last_row) * hop);
+    const int fin_valid = fin_left < (1 << 30) ? static_cast<int>(fin_left) : (1 << 30);
+    const int k_fin0 = fin_valid / 16;                 // first piece that holds a frame >= fin_valid
+    // (nothing per-lane is kept for this: the rare steps recompute what they need from the lane id)
+
     // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
     if constexpr (DO_TP) {
 #pragma unroll
@@ -561,6 +577,16 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(my_lds + ((c ^ rd_swz) * 16));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (fin_wave && k >= k_fin0) {  // (wave-uniform; the last two steps of a wave that holds a track's final hop)
+            const int lim = lane >= last_row ? fin_valid - 16 * k : (1 << 30);  // frames of this piece that exist (idle lanes shadow the last row)
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                v[c].x = 2 * c < lim ? v[c].x : 0.0f;
+                v[c].y = 2 * c < lim ? v[c].y : 0.0f;
+                v[c].z = 2 * c + 1 < lim ? v[c].z : 0.0f;
+                v[c].w = 2 * c + 1 < lim ? v[c].w : 0.0f;
+            }
+        }
         // the last piece of a hop may be partial (44.1 kHz: 4410 = 275*16 + 10): K-weight its frames one at a
         // time straight from LDS, before the buffer is handed back to the DMA
         if (DO_KW && rem && k == T_full) {
@@ -595,8 +621,23 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
         if (k < T && !HR_DBG(dbg, 16)) {
             const char *src = wave_base + (HR_DBG(dbg, 32) ? 0 : static_cast<size_t>(k + 1) * PB);  // dbg 32 (experiments): re-read piece 0 (cache hits)
+            if (fin_wave && k + 1 >= k_fin0) {
+                // piece k+1 of the final row reaches past the track: chunks that start beyond its end are not fetched
+                const int end_bytes = fin_valid * static_cast<int>(FB) - (k + 1) * static_cast<int>(PB);  // bytes of this piece that exist
 #pragma unroll
-            for (int j = 0; j < NDMA; j++) dma16(src, dma_off[j], lbuf + j * 1024);
+                for (int j = 0; j < NDMA; j++) {
+                    // (the DMA geometry above: which row and which source chunk this lane serves in instruction j)
+                    const int gi = 64 * j + lane;
+                    const int slot = INF == 2 ? gi / 6 : (64 / NDMA) * j + lane / LPP;
+                    const int chunk = INF == 2 ? (gi % 6 + 6 - ((slot >> 3) & 1)) % 6
+                                    : INF == 1 ? ((lane & 3) ^ ((slot >> 2) & 3)) : ((lane & 7) ^ ((slot >> 1) & 7));
+                    const bool oob = slot >= last_row && chunk * 16 >= end_bytes;
+                    if (!oob) dma16(src, dma_off[j], lbuf + j * 1024);  // (inactive lanes transfer nothing: their LDS slots keep stale bytes)
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < NDMA; j++) dma16(src, dma_off[j], lbuf + j * 1024);
+            }
             if constexpr (DO_KW) {
                 if (wave == 0) dma16(gsrc + static_cast<size_t>(k + 1) * 512, lane16, gbuf + ((k + 1) & 1) * kCarryLds);
             }
@@ -773,6 +814,22 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 }
             }
         };
+        // Tiles T-2 and T-1 (screened at steps T-1 and T) of a final row reach into frames that do not exist: that row's
+        // columns of the signal fragments become zeros, so its outputs of these two tiles are exact zeros -- no bound, no
+        // candidate.  (A lane's fragments of n-tile nt belong to wave row 32*nt + (lane & 31); the row's remaining
+        // positions stay with the generic kernel.)
+        if (DO_TP && fin_wave && k >= T - 1) {
+#pragma unroll
+            for (int nt = 0; nt < 2; nt++) {
+                const bool drop = 32 * nt + (lane & 31) >= last_row;
+#pragma unroll
+                for (int a = 0; a < 3; a++)
+#pragma unroll
+                    for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) hist[a][ch][nt][q] = drop ? 0u : hist[a][ch][nt][q];
+            }
+        }
         const bool fused_step = DO_KW && k < T_full;
 #if defined(HR_EXP_PRIO) && HR_EXP_PRIO == 2
         __builtin_amdgcn_s_setprio(3);
@@ -866,7 +923,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 const float Sf = wave_max_f32(s_lane[c]);
-                if (lane == 0 && Sf > 0.0f)
+                if (lane == 0 && n_rows > 0 && Sf > 0.0f)
                     atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
                               static_cast<unsigned long long>(__double_as_longlong(static_cast<double>(Sf))));
             }
@@ -881,8 +938,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             Af[c] = wave_max_f32(alb[c]);
             lb[c] = fmaxf(lb[c], fmaxf(passthru0 ? Sf[c] : 0.0f, Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
         }
-        if (lane == 0) {
-            cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
+        if (lane == 0) cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
+        if (lane == 0 && n_rows > 0) {  // (padding waves list nothing and report nothing)
             if (n_cand > kCandCap || Sf[0] >= kF16Safe || Sf[1] >= kF16Safe) overflow[it.track] = 1u;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
