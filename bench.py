@@ -60,6 +60,24 @@ def cpu_baseline(n_tracks, threads):
                       f"one thread per track, oracle mode ebur128 gating + 192 kHz interpolation, {dt:.2f} s wall"}, res, tracks
 
 
+def valu_ceiling(bytes_per_step, kernel_ms):
+    """SURVEY 8(d) "min(HBM, VALU)": what the vector ALU lets the fused kernel reach, beside the HBM fraction.  The
+    per-sample instruction counts and the clock are the committed measurements of profiles/README.md (round 2: ISA count
+    of the hot block, SQ_ACTIVE_INST_VALU and GRBM_GUI_ACTIVE passes on a 200-track launch); a full-rate VALU
+    instruction occupies a SIMD for 4 cycles per 64-lane wave (profiles/r1_microbench2.txt: 2.2-2.6 ns per f64 FMA)."""
+    simds, lanes_per_cycle = 256 * 4, 16
+    f64_ops, valu_slots = 13.0, 21.2          # per 4-byte sample: 12 f64 FMA/MUL/ADD + 1 convert; all VALU issue slots (PMC)
+    clk_obs, clk_max = 1.60e9, 2.4e9          # GRBM_GUI_ACTIVE / 8 / duration under the kernel; data-sheet maximum
+    def gbs(ops, clk):
+        return simds * lanes_per_cycle * clk / ops * 4.0 / 1e9
+    return {"f64_ops_per_sample": f64_ops, "valu_issue_slots_per_sample": valu_slots, "cycles_per_wave_instruction": 4,
+            "clock_observed_ghz": clk_obs / 1e9, "clock_max_ghz": clk_max / 1e9,
+            "ceiling_gbs_at_observed_clock": gbs(valu_slots, clk_obs), "ceiling_gbs_at_max_clock": gbs(valu_slots, clk_max),
+            "f64_only_ceiling_gbs_at_observed_clock": gbs(f64_ops, clk_obs),
+            "frac_of_valu_ceiling": (bytes_per_step / (kernel_ms * 1e-3) / 1e9) / gbs(valu_slots, clk_obs) if kernel_ms > 0 else None,
+            "source": "profiles/README.md round 2 (SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE passes; the kernel runs power-limited at the observed clock)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -192,13 +210,13 @@ def main():
         kernel_ms = sum(main_ms) / max(len(main_ms), 1)
         achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM bytes per launch of the fused kernel: PMC counters need a profiler pass of their own, so this is the
-        # committed measurement (profiles/r1_fused_hbm_traffic.json, bytes per track) scaled to this launch
+        # committed measurement (profiles/r2_fused_hbm_traffic.json, bytes per track) scaled to this launch
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_fused_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_fused_hbm_traffic.json")
         if os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32" and SECONDS == 180 and not args.ragged:
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_track"] * n_tracks
-            traffic_src = "profiles/r1_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
+            traffic_src = "profiles/r2_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
         line = {
             "metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": value, "unit": "audio-hours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -214,6 +232,9 @@ def main():
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
+        if args.pcm_format == "f32" and args.tp_mode == "swr192k":
+            line["roofline"]["valu"] = valu_ceiling(bytes_per_step, kernel_ms)
+            line["roofline"]["binding_ceiling"] = "valu" if line["roofline"]["valu"]["ceiling_gbs_at_observed_clock"] < HBM_PEAK_GBS else "hbm"
         if (world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2" and args.tp_mode == "swr192k"
                 and SECONDS == 180 and not args.ragged):
             # one thread per core of the job's CPU share: the scheduler's affinity mask when it is narrower than the

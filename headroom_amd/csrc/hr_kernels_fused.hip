@@ -45,7 +45,8 @@
 #else
 #define HR_DBG(dbg, bit) false
 #if defined(HR_EXP_NO_FRAGS) || defined(HR_EXP_NO_MFMA) || defined(HR_EXP_NO_KW) || defined(HR_EXP_NO_REDUCE) || \
-    defined(HR_EXP_NO_AF) || defined(HR_EXP_NO_BARRIER) || defined(HR_EXP_NO_VMWAIT) || defined(HR_EXP_PRIO)
+    defined(HR_EXP_NO_AF) || defined(HR_EXP_NO_BARRIER) || defined(HR_EXP_NO_VMWAIT) || defined(HR_EXP_PRIO) || \
+    defined(HR_EXP_NO_Q) || defined(HR_EXP_NO_COEF_DMA) || defined(HR_EXP_NO_CAND) || defined(HR_EXP_NO_BOUNDS) || defined(HR_EXP_NO_MFMA2) || defined(HR_EXP_PCM_AUX) || defined(HR_EXP_COEF_PAT0)
 #error "HR_EXP_* switches need -DHR_EXPERIMENTS"
 #endif
 #endif
@@ -216,8 +217,12 @@ __device__ __forceinline__ void kw_sample_short(KState &s, const KCoef &k, float
     v = fma(-k.ra2, s.z2, v);
     const double z0 = fma(-k.ra1, s.z1, v);
     s.e0 = fma(z0, z0, s.e0);
+#ifndef HR_EXP_NO_Q
     s.q2 = fma(z0, g2, s.q2);
     s.q3 = fma(z0, g3, s.q3);
+#else
+    (void)g2; (void)g3;
+#endif
     s.x2 = s.x1; s.x1 = x0;
     s.y2 = s.y1; s.y1 = y0;
     s.z2 = s.z1; s.z1 = z0;
@@ -226,12 +231,18 @@ __device__ __forceinline__ void kw_sample_short(KState &s, const KCoef &k, float
 // LDS-DMA of 16 bytes per lane: global (uniform base + 32-bit lane offset) -> LDS (uniform base + lane*16).
 // The offset passes through an empty asm so that its zero-extension stays next to the add and the
 // instruction is selected in its scalar-base form (no 64-bit vector address arithmetic per DMA).
+template <int AUX = 0>
 __device__ __forceinline__ void dma16(const char *base, unsigned lane_off, char *lds)
 {
     asm volatile("" : "+v"(lane_off));
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(base + lane_off),
-                                     (__attribute__((address_space(3))) void *)lds, 16, 0, 0);
+                                     (__attribute__((address_space(3))) void *)lds, 16, 0, AUX);
 }
+#ifdef HR_EXP_PCM_AUX
+#define HR_PCM_AUX HR_EXP_PCM_AUX
+#else
+#define HR_PCM_AUX 0
+#endif
 
 // MT: 32-output blocks per tile (1..3); SMALL: the last block holds at most 8 outputs (44.1 kHz: outputs 64..69
 // of 70), so only the first four accumulator registers of its groups can be non-zero.
@@ -509,6 +520,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     // This wave's share (chunks i with i mod 4 == wave) of the coefficients of the tile that step k+1 screens,
     // into the half of the coefficient area that step k does not read.
     auto issue_coeff = [&](int pattern, int k, int kmod3) {
+#ifdef HR_EXP_COEF_PAT0
+        pattern = 0;
+#endif
         const char *asrc = reinterpret_cast<const char *>(r.tp_atab) + static_cast<size_t>(pattern) * MT * 3 * 1024;
         char *dst = abuf + ((k + 1) & 1) * kCoefLds;
 #pragma unroll
@@ -636,13 +650,15 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 }
             } else {
 #pragma unroll
-                for (int j = 0; j < NDMA; j++) dma16(src, dma_off[j], lbuf + j * 1024);
+                for (int j = 0; j < NDMA; j++) dma16<HR_PCM_AUX>(src, dma_off[j], lbuf + j * 1024);
             }
             if constexpr (DO_KW) {
                 if (wave == 0) dma16(gsrc + static_cast<size_t>(k + 1) * 512, lane16, gbuf + ((k + 1) & 1) * kCarryLds);
             }
             if constexpr (DO_TP) {
+#ifndef HR_EXP_NO_COEF_DMA
                 issue_coeff(pat, k, KK);
+#endif
                 pat = pat + 1 == NP ? 0 : pat + 1;
             }
         }
@@ -666,7 +682,12 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             // (one compare: a VALU compare that feeds a scalar branch costs as much as half a dozen f32 operations)
             const float over = fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1]));
             const bool stale = over > 0.0f;
+#ifdef HR_EXP_NO_BOUNDS
+            asm volatile("" :: "v"(over));
+            if (k == 0) refresh_bounds();
+#else
             if (__ballot(stale) != 0ull) refresh_bounds();
+#endif
         }
 
         // ---- the hot block, branch-free so that the scheduler can run the f64 K-weighting of piece k under
@@ -717,15 +738,21 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                     o.r[2] = lds_ld128(g_at, (2 * c + 1) * 32);
                     o.r[3] = lds_ld128(g_at, (2 * c + 1) * 32 + 16);
                 } else {
+#ifndef HR_EXP_NO_Q
                     o.r[1] = lds_ld128(g_at, (2 * c) * 32 + 16);
                     o.r[3] = lds_ld128(g_at, (2 * c + 1) * 32 + 16);
+#else
+                    o.r[1] = o.r[3] = uint4v{0, 0, 0, 0};
+#endif
                     o.r[0] = o.r[2] = uint4v{0, 0, 0, 0};
                 }
                 return o;
             };
             auto wait_gc = [&](GC &g) {
                 if constexpr (!SHORT) lds_wait(g.r[0], g.r[1], g.r[2], g.r[3]);
+#ifndef HR_EXP_NO_Q
                 else lds_wait(g.r[1], g.r[3]);
+#endif
             };
             // sample i of slice c: i = 0, 1 are the two channels of frame 2c, i = 2, 3 of frame 2c+1
             auto ksample = [&](int c, int i, const GC &g) {
@@ -760,7 +787,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
 #pragma unroll
                 for (int k3 = 0; k3 < 3; k3++) {
                     if constexpr (DO_TP) {
-#ifndef HR_EXP_NO_MFMA
+#if defined(HR_EXP_NO_MFMA2)
+                        asm volatile("" : "+v"(acc) : "v"(af[k3]), "v"(hist[k3][ch][nt]));
+#elif !defined(HR_EXP_NO_MFMA)
                         acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(as_half8(af[k3]), as_half8(hist[k3][ch][nt]), acc, 0, 0, 0);
 #else
                         acc[k3] += __uint_as_float(af[k3][0] ^ hist[k3][ch][nt][0]);
@@ -858,7 +887,12 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                     for (int mt = 1; mt < MT; mt++) mm = fmaxf(mm, m0[mt][ch][nt]);
                     margin = fmaxf(margin, mm - thr_l[ch][nt]);
                 }
+#ifdef HR_EXP_NO_CAND
+            asm volatile("" :: "v"(margin));
+            const unsigned long long any = 0ull;
+#else
             const unsigned long long any = __ballot(margin >= 0.0f);
+#endif
             if (any != 0ull && !HR_DBG(dbg, 1)) {  // wave-uniform, rare
 #pragma unroll
                 for (int mt = 0; mt < MT; mt++)
@@ -1422,7 +1456,11 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
     k_fused_f32s<DO_KW, DO_TP, MT, SMALL, INF><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, \
                                                                           fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg)
 #ifdef HR_FAST_BUILD
-    if constexpr (DO_KW && DO_TP && INF == 0) { HR_FUSED_CASE(3, true); }
+#ifndef HR_FAST_MT
+#define HR_FAST_MT 3
+#define HR_FAST_SMALL true
+#endif
+    if constexpr (DO_KW && DO_TP && INF == 0) { HR_FUSED_CASE(HR_FAST_MT, HR_FAST_SMALL); }
     (void)tp_class;
 #else
     if constexpr (!DO_TP) {
