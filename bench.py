@@ -156,7 +156,8 @@ def main():
     frames = int(FS * SECONDS) + args.ragged
     # HR_BENCH_OFFSET (experiments): byte offset of every track inside its slot, to see what cache-line alignment is worth
     boff = int(os.environ.get("HR_BENCH_OFFSET", "0"))
-    pcm = torch.empty((n_tracks, frames + (16 if boff else 0), CH), dtype=torch.float32, device=dev)
+    # (every track starts on a 16-byte boundary, as separately allocated buffers would: the stride is an even frame count)
+    pcm = torch.empty((n_tracks, (frames + 1) // 2 * 2 + (16 if boff else 0), CH), dtype=torch.float32, device=dev)
     for i in range(n_tracks):
         meter.synth_fill(pcm[i].data_ptr() + boff, 1000 + rank * n_tracks + i, FS, CH, frames)
     torch.cuda.synchronize()

@@ -107,7 +107,8 @@ struct hr_ctx {
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items;
     std::vector<FusedItem> h_fitems;
-    std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel (2: the final hop too)
+    std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
+    std::vector<uint64_t> h_fend;     // ... which screened the positions in front of this one (redo_overflowed_peaks)
     std::vector<WorkItem> h_ovf_items, h_gate_items;
     bool no_s16_direct = false;  // HR_NO_S16_DIRECT=1: stereo s16 is widened into f32 planes first, as before
     // the next three are set only by the experiments library (-DHR_EXPERIMENTS, make exp); always false / 0 in the shipped one
@@ -295,9 +296,6 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     if (!ctx->hop_sums.ensure((g.hop_slots + 8) * sizeof(double))) return HR_ERR_OOM;
     if (!ctx->blk_powers.ensure(std::max<uint64_t>(g.blk_slots, 1) * sizeof(double))) return HR_ERR_OOM;
     if (!ctx->peaks.ensure(nt * kMaxCh * sizeof(unsigned long long))) return HR_ERR_OOM;
-    int rc = upload(ctx->tracks_d, g.descs.data(), nt * sizeof(TrackDesc), st);
-    if (rc) return rc;
-    const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
     const RateDev *dr = ctx->rates_d.as<RateDev>();
 
     // Which tracks take the fused kernel (hr_kernels_fused.hip)?  Stereo f32, 16-byte aligned, at least two
@@ -320,17 +318,47 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     // The track's final hop joins the fused rows (instead of the generic one-lane-per-hop kernel) when the stream ends
     // with this track and the fused kernel can keep the row honest (hr_kernels_fused.hip, "FINAL hop"): either the ragged
-    // tail is long enough that every byte the row touches exists (22 frames: the row reads 16*(T+1) - hop <= 22 frames
-    // past the hop), or the row's 16-byte chunks are 16-byte aligned, so that a chunk that STARTS inside the track never
-    // crosses a page behind its end.
+    // tail is long enough that every byte the row touches exists (the row reads 16 (T + 1) - hop <= 31 frames past the
+    // hop), or the track's image ends on a 16-byte boundary, so that a chunk that STARTS inside the track ends inside it.
+    // And the ragged tail behind it becomes one more row (row n_hops, for its true peak only: no block ends in it) when it
+    // is worth a lane: the row holds the tail's frames up to the last 16-byte boundary of the track's image (fin_valid), its
+    // tiles are screened as far as their windows stay inside those frames and in front of the positions that produce no
+    // output, and the generic kernel starts at the first tile that is not (fend).
     std::vector<uint8_t> ffin(nt, 0);
+    std::vector<uint64_t> &fend = ctx->h_fend;  // fused tracks: first position the fused kernel does not screen
+    fend.assign(nt, 0);
     for (size_t i = 0; i < nt; i++) {
-        const TrackDesc &d = g.descs[i];
-        if (!fkw[i] || !d.stream_end || d.right_head || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
+        TrackDesc &d = g.descs[i];
+        d.fin_tail = 0;
+        d.fin_valid = 0;
+        if (!fkw[i]) continue;
+        const uint64_t last_hop0 = (d.n_hops - 1) * d.hop;
+        fend[i] = last_hop0;
+        if (!d.stream_end || d.right_head || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
         const uint64_t ragged = d.frames - d.n_hops * d.hop;
-        const uint64_t row_bytes = static_cast<uint64_t>(d.hop) * fmt_bytes(d.fmt) * 2;
-        ffin[i] = ragged >= 22 || row_bytes % 16 == 0;
+        const uint32_t fb = fmt_bytes(d.fmt) * 2;
+        const uint64_t T = (d.hop + 15) / 16;
+        const uint64_t align = fb == 8 ? 2 : fb == 4 ? 4 : 8;  // frames per 16 bytes of f32 / s16 / s24 stereo (s24: of 48)
+        // (a row fetches pieces 0 .. T: 16 (T + 1) frames from its start)
+        ffin[i] = d.frames - last_hop0 >= 16 * (T + 1) || d.frames % align == 0;
+        if (!ffin[i]) continue;
+        const uint64_t usable = d.frames / align * align - d.n_hops * d.hop;  // (only meaningful when ragged >= align)
+        if (ftp[i] && ragged >= 64 && usable >= 48 && usable < d.hop) {
+            d.fin_tail = 1;
+            d.fin_valid = static_cast<uint32_t>(usable);
+            const uint64_t keep = usable > d.tp_drop ? usable - d.tp_drop : 0;
+            fend[i] = d.n_hops * d.hop + 16 * (keep / 16);
+        } else {
+            const uint64_t left = d.frames - last_hop0;
+            d.fin_valid = static_cast<uint32_t>(std::min<uint64_t>(left, 1u << 30));
+            const uint64_t keep = d.fin_valid > d.tp_drop ? d.fin_valid - d.tp_drop : 0;
+            // (the sample-peak build takes no part in this: its generic kernel starts where it always did)
+            fend[i] = last_hop0 + 16 * (ftp[i] ? std::min<uint64_t>(keep / 16, T) : T - 2);
+        }
     }
+    int rc = upload(ctx->tracks_d, g.descs.data(), nt * sizeof(TrackDesc), st);
+    if (rc) return rc;
+    const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
@@ -348,12 +376,12 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                 const RateDev &rd = ctx->rates_h[ri];
                 const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
-                const uint64_t interior = g.descs[i].n_hops - (ffin[i] ? 0 : 1);
+                const uint64_t interior = g.descs[i].n_hops - (ffin[i] ? 0 : 1) + g.descs[i].fin_tail;
                 for (uint64_t h = 0; h < interior; h += 64)
                     fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
             }
             if (fitems.size() > run_begin)
-                while ((fitems.size() - run_begin) % 4) {
+                while ((fitems.size() - run_begin) % kFusedWaves) {
                     FusedItem pad = fitems.back();
                     pad.n_rows = 0;
                     fitems.push_back(pad);
@@ -408,10 +436,9 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     if (g.fmts[i] != f || g.descs[i].role == 1) continue;
                     const bool plain = ctx->cfg.tp_mode != HR_TP_SAMPLE && ctx->rates_h[g.descs[i].rate_idx].swr_phases == 0;
                     if (plain != (kind == 1)) continue;
-                    // fused tracks: the generic kernel finishes the track -- from the last hop on, or, when the final hop
-                    // is a fused row too, from the first position of its tile T-2 (the last two tiles are not screened there)
-                    const uint64_t last_hop0 = (g.descs[i].n_hops - 1) * g.descs[i].hop;
-                    const uint64_t n0 = !(ftp[i] || fsp[i]) ? 0 : !ffin[i] ? last_hop0 : last_hop0 + 16ull * ((g.descs[i].hop + 15) / 16 - 2);
+                    // fused tracks: the generic kernel finishes the track -- from the last hop on, or, when the last rows
+                    // are fused too, from the first position of the first tile that is not screened there
+                    const uint64_t n0 = !(ftp[i] || fsp[i]) ? 0 : fend[i];
                     // (the tail of a fused track is cut into short items: many brief workgroups beside the fused kernel
                     // instead of one long-running one)
                     const uint32_t span = ftp[i] && kind == 0 ? kTailSpan : 0;
@@ -440,8 +467,6 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
     }
     ctx->h_ftp.assign(ftp.begin(), ftp.end());
-    for (size_t i = 0; i < nt; i++)
-        if (ftp[i] && ffin[i]) ctx->h_ftp[i] = 2;  // (the fused rows reach into the final hop: redo_overflowed_peaks)
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
@@ -606,9 +631,8 @@ int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
     for (int f = 0; f < 3; f++) {
         for (size_t i = 0; i < nt; i++) {
             if (!ctx->h_ftp[i] || !ovf[i] || g.fmts[i] != f) continue;
-            // everything the fused kernel screened: up to the last hop, or (final hop fused too) up to its tile T-2
-            uint64_t end = (g.descs[i].n_hops - 1) * g.descs[i].hop;
-            if (ctx->h_ftp[i] == 2) end += 16ull * ((g.descs[i].hop + 15) / 16 - 2);
+            // everything the fused kernel screened
+            const uint64_t end = ctx->h_fend[i];
             for (uint64_t n = 0; n < end; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
         }
         fmt_end[f] = items.size();

@@ -13,6 +13,12 @@ constexpr int kPreBlk = 3;   // of those, the last 3 are recomputed from the nei
 constexpr int kHalo = 16;    // frames of FIR halo on each side of a shard
 constexpr int kEbuBins = 8001;
 constexpr int kLnBins = 1000;
+// waves per workgroup of the fused kernel (they share the rate's coefficient tiles and carry table in LDS); the host pads
+// every run of same-rate items to a multiple of it
+#ifndef HR_WG_WAVES
+#define HR_WG_WAVES 4
+#endif
+constexpr int kFusedWaves = HR_WG_WAVES;
 constexpr uint32_t kGateChunk = 16384;  // 400 ms blocks (and 3 s windows) per gating workgroup: a 3-minute track is one chunk
 
 // what one gating chunk hands to the per-track finalisation (summed there in chunk order: reproducible)
@@ -76,13 +82,14 @@ struct TrackDesc {
     uint8_t tp_enabled;    // resampler produces output at all (swr: stream >= 33 frames)
     uint8_t tp_reflect;    // frames in front of the stream are its mirror image (libswresample) instead of silence
     uint8_t tp_drop;       // positions at the stream end that produce no output (swr: 16, no flush; BS.1770: 0)
-    uint8_t pad2_;
+    uint8_t fin_tail;      // 1: the ragged tail behind the last whole hop is a row of the fused kernel too (row n_hops; peak only)
     uint8_t role;          // 0 ordinary track; 1 parent of stereo planes (measured through them: no work items of its
                            // own, only hop-sum slots and gating); 2 stereo plane of a parent
     uint32_t first_plane;  // role 1: index of the first of its (ch+1)/2 consecutive plane descriptors
     int32_t st_pre;        // hop sums in front of hop 0 that are valid for the 3 s windows: 0, or kPreHop for a shard whose
                            // left neighbour handed over its last 29
-    uint32_t pad3_;
+    uint32_t fin_valid;    // fused tracks whose last rows are fused: frames of the LAST fused row, from its start, that exist and may
+                           // be fetched (16-byte chunks that start inside them end inside the track)
     uint64_t first_hop;    // index of hop 0 in the whole stream (libebur128 takes its range blocks on a 1 s grid)
     uint32_t part_base, n_parts;  // gating chunks of kGateChunk blocks (one workgroup each): slots of their partial sums
     float w[kMaxCh];

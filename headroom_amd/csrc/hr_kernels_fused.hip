@@ -67,7 +67,7 @@ typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 //   2 x 9 KiB   coefficient tiles of the tile being screened / the next one, shared by the four waves
 //   2 x 1 KiB   carry-table slice of this step / the next one, shared
 constexpr int kPieceLds = 8192, kCoefLds = 9 * 1024, kCarryLds = 1024;
-constexpr int kGroupLds = 4 * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
+constexpr int kGroupLds = kFusedWaves * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
 constexpr int kFmtF32 = 0, kFmtS16 = 1, kFmtS24 = 2;  // HR_FMT_F32, HR_FMT_S16, HR_FMT_S24 of include/headroom_hip.h
 constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
 
@@ -243,6 +243,17 @@ __device__ __forceinline__ void dma16(const char *base, unsigned lane_off, char 
 #else
 #define HR_PCM_AUX 0
 #endif
+#if defined(HR_FAST_BUILD) && !defined(HR_FAST_MT)
+#define HR_FAST_MT 3
+#define HR_FAST_SMALL true
+#endif
+#ifdef HR_FAST_MT
+#define HR_FAST_MT_OR_3 HR_FAST_MT
+#define HR_FAST_SMALL_OR_TRUE HR_FAST_SMALL
+#else
+#define HR_FAST_MT_OR_3 3
+#define HR_FAST_SMALL_OR_TRUE true
+#endif
 
 // MT: 32-output blocks per tile (1..3); SMALL: the last block holds at most 8 outputs (44.1 kHz: outputs 64..69
 // of 70), so only the first four accumulator registers of its groups can be non-zero.
@@ -307,7 +318,7 @@ __device__ __forceinline__ float s24_sample(const unsigned (&w)[25])
 }
 
 template <bool DO_KW, bool DO_TP, int MT, bool SMALL, int INF = 0>
-__global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restrict__ tracks,
+__global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32s(const TrackDesc *__restrict__ tracks,
                                                        const RateDev *__restrict__ rates,
                                                        const FusedItem *__restrict__ items, uint32_t n_items,
                                                        HopRec *__restrict__ recs, uint2 *__restrict__ cands,
@@ -322,7 +333,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     extern __shared__ __attribute__((aligned(16))) char smem[];  // kGroupLds
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t item_idx = blockIdx.x * 4 + wave;
+    const uint32_t item_idx = blockIdx.x * kFusedWaves + wave;
     // (the host pads every rate's item list to a multiple of 4 with n_rows == 0 items: the four waves of a
     // workgroup share tables and a barrier per step, so all of them run all steps)
     const FusedItem it = items[item_idx];
@@ -345,7 +356,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     constexpr int LPP = PB / 16;                // lanes per piece
     const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * static_cast<unsigned long long>(FB);
     char *lbuf = smem + wave * kPieceLds;
-    char *abuf = smem + 4 * kPieceLds;    // [2][9 KiB]: step k reads half k&1
+    char *abuf = smem + kFusedWaves * kPieceLds;    // [2][9 KiB]: step k reads half k&1
     char *gbuf = abuf + 2 * kCoefLds;     // [2][1 KiB]: step k reads half k&1
     const char *gsrc = reinterpret_cast<const char *>(r.g);  // 512 B (16 frames x 4 doubles) per step
     const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
@@ -372,20 +383,34 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     const unsigned rd_swz = INF == 2 ? (lane >> 3) & 1 : INF == 1 ? (lane >> 2) & 3 : (lane >> 1) & 7;  // s24: a rotation, not an xor
     const char *my_lds = lbuf + lane * PB;
 
-    // ---- the track's FINAL hop as a row (the host puts it here when the stream ends with this track and, see
-    // run_measure, the row's pieces are 16-byte aligned or the ragged tail is long enough).  Its pieces T-1 and T reach
-    // past the hop, possibly past the track: frames at or beyond fin_valid (frames from the row's start to the track's end)
-    // do not exist.  Three things keep the row honest, all behind wave-uniform branches in the last three steps:
-    //   * DMA lanes whose 16-byte chunk starts at or beyond the track's end are switched off (their LDS slots keep stale bytes);
+    // ---- the track's LAST rows (host: run_measure).  When the stream ends with this track its final hop is a row too, and
+    // so is the ragged tail behind it when it is long enough (TrackDesc::fin_tail: row n_hops, there for its peak only).
+    // The last fused row reaches past the frames that exist: TrackDesc::fin_valid = frames of that row, from its start, that
+    // exist and may be fetched (the host makes a 16-byte chunk that starts inside them end inside the track);
+    // fin_keep = fin_valid - tp_drop = its frames that are positions of an output (libswresample is not flushed: the last 16
+    // are not).  Behind wave-uniform branches, in the last steps of that one wave:
+    //   * DMA lanes whose 16-byte chunk starts at or beyond fin_valid are switched off (their LDS slots keep stale bytes);
     //   * frames >= fin_valid are zeroed as they leave LDS (they never reach the sample peak or the f16 fragments);
-    //   * the tiles T-2 and T-1, whose windows reach into those frames, are not screened for this row: their positions
-    //     (and the ragged tail) stay with the bounds-checked generic kernel, which the host starts at position 16*(T-2).
-    // (a padding item, n_rows == 0, works on row 0 of the item it copies: when that is a one-row wave holding a final
-    // hop, the padding wave needs the same care -- it reads the same bytes)
-    const bool fin_wave = it.first_hop + static_cast<uint64_t>(last_row + 1) == t.n_hops;
-    const long long fin_left = static_cast<long long>(t.frames) - static_cast<long long>((it.first_hop + last_row) * hop);
-    const int fin_valid = fin_left < (1 << 30) ? static_cast<int>(fin_left) : (1 << 30);
-    const int k_fin0 = fin_valid / 16;                 // first piece that holds a frame >= fin_valid
+    //   * frames in [fin_keep, fin_valid) are real and bound the screen's error (S_x) but are no sample peak;
+    //   * tiles from fin_keep / 16 on, whose positions produce no output or whose windows reach past fin_valid, are not
+    //     screened for this row: the bounds-checked generic kernel starts at the first of them.
+    // (a padding item, n_rows == 0, works on row 0 of the item it copies: when that is a one-row wave holding a last
+    // row, the padding wave needs the same care -- it reads the same bytes)
+    // One number stays live for all of this: k_fin, the first step that needs any care (the piece that holds frame
+    // fin_keep; never, in every other wave).  The rare steps fetch the rest from the descriptor again.
+    const bool fin_wave = it.first_hop + static_cast<uint64_t>(last_row + 1) == t.n_hops + t.fin_tail;
+    const int k_fin = fin_wave ? (static_cast<int>(t.fin_valid) > t.tp_drop ? (static_cast<int>(t.fin_valid) - t.tp_drop) / 16 : 0) : (1 << 30);
+    auto fin_valid_now = [&]() {
+        const TrackDesc *tp = &t;
+        asm volatile("" : "+s"(tp));  // (not hoisted out of the rare branch)
+        return static_cast<int>(tp->fin_valid);
+    };
+    auto fin_keep_now = [&]() {
+        const TrackDesc *tp = &t;
+        asm volatile("" : "+s"(tp));
+        const int fv = static_cast<int>(tp->fin_valid), drop = tp->tp_drop;
+        return fv > drop ? fv - drop : 0;
+    };
     // (nothing per-lane is kept for this: the rare steps recompute what they need from the lane id)
 
     // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
@@ -464,6 +489,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
     float S_u[2] = {-1.0f, -1.0f};   // wave maximum of s_lane at the last refresh
     float A_u[2] = {0.0f, 0.0f};     // wave maximum of alb at the last refresh
     float lb[2] = {0.0f, 0.0f};      // proven lower bound of the channel's true peak
+    float S_x[2] = {0.0f, 0.0f};     // wave-uniform: max |x| of the final row's frames that are read but are no output samples
     float thr_l[2][2];               // [ch][n-tile] candidate threshold of this lane's column; +inf past n_rows
 #pragma unroll
     for (int c = 0; c < 2; c++) thr_l[c][0] = thr_l[c][1] = __builtin_inff();
@@ -476,23 +502,40 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         for (int ch = 0; ch < 2; ch++) {
             S_u[ch] = wave_max_f32(s_lane[ch]);
             A_u[ch] = wave_max_f32(alb[ch]);
-            const float err = fmaf(kScreenRel, S_u[ch], kScreenAbs);
+            const float err = fmaf(kScreenRel, fmaxf(S_u[ch], S_x[ch]), kScreenAbs);
             lb[ch] = fmaxf(lb[ch], fmaxf(passthru0 ? S_u[ch] : 0.0f, A_u[ch] - err));
             const float thr = fmaxf(lb[ch] - err, 1e-30f);  // silence is never a candidate; |x| beyond f16 -> overflow flag
             thr_l[ch][0] = (lane & 31) < n_rows ? thr : __builtin_inff();
             thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
         }
     };
-    auto make_frags = [&](auto slot_c) {
+    // keep: frames of this piece (from its first) that count as samples of the output; the others (the final row's, in
+    // the positions libswresample never reaches) go into S_x instead of the lane's sample peak
+    auto make_frags = [&](auto slot_c, auto masked_c, int keep) {
         constexpr int slot = decltype(slot_c)::value;
+        constexpr bool MASKED = decltype(masked_c)::value;
 #ifdef HR_EXP_NO_FRAGS
         if constexpr (DO_TP) { hist[slot][0][0][0] ^= __float_as_uint(v[0].x); return; }
 #endif
         if constexpr (DO_TP) {
+            if constexpr (MASKED) {
+                float ex[2] = {0.0f, 0.0f};
 #pragma unroll
-            for (int c = 0; c < 8; c++) {
-                s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
-                s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
+                for (int c = 0; c < 8; c++) {
+                    const bool k0 = 2 * c < keep, k1 = 2 * c + 1 < keep;
+                    s_lane[0] = fmaxf(fmaxf(k0 ? fabsf(v[c].x) : 0.0f, k1 ? fabsf(v[c].z) : 0.0f), s_lane[0]);
+                    s_lane[1] = fmaxf(fmaxf(k0 ? fabsf(v[c].y) : 0.0f, k1 ? fabsf(v[c].w) : 0.0f), s_lane[1]);
+                    ex[0] = fmaxf(fmaxf(k0 ? 0.0f : fabsf(v[c].x), k1 ? 0.0f : fabsf(v[c].z)), ex[0]);
+                    ex[1] = fmaxf(fmaxf(k0 ? 0.0f : fabsf(v[c].y), k1 ? 0.0f : fabsf(v[c].w)), ex[1]);
+                }
+                S_x[0] = fmaxf(S_x[0], wave_max_f32(ex[0]));
+                S_x[1] = fmaxf(S_x[1], wave_max_f32(ex[1]));
+            } else {
+#pragma unroll
+                for (int c = 0; c < 8; c++) {
+                    s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
+                    s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
+                }
             }
             unsigned f[2][8];
 #pragma unroll
@@ -510,7 +553,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
                 }
         }
     };
-    make_frags(std::integral_constant<int, 2>{});  // the prologue piece is "piece -1"
+    make_frags(std::integral_constant<int, 2>{}, std::false_type{}, 16);  // the prologue piece is "piece -1"
 
     // tile bookkeeping (wave-uniform): the coefficient pattern of tile t is t mod NP
     const int NP = r.tp_np;
@@ -529,7 +572,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int ksx = 0; ksx < 3; ksx++)
-                if (((mt * 3 + ksx) & 3) == wave)
+                if (((mt * 3 + ksx) % kFusedWaves) == wave)
                     dma16(asrc + (mt * 3 + ksx) * 1024, lane16, dst + (mt * 3 + (kmod3 + 2 + ksx) % 3) * 1024);
     };
 
@@ -591,8 +634,8 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             for (int c = 0; c < 8; c++) v[c] = *reinterpret_cast<const float4 *>(my_lds + ((c ^ rd_swz) * 16));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if (fin_wave && k >= k_fin0) {  // (wave-uniform; the last two steps of a wave that holds a track's final hop)
-            const int lim = lane >= last_row ? fin_valid - 16 * k : (1 << 30);  // frames of this piece that exist (idle lanes shadow the last row)
+        if (k >= k_fin) {  // (wave-uniform; the last steps of the wave that holds a track's last fused row)
+            const int lim = lane >= last_row ? fin_valid_now() - 16 * k : (1 << 30);  // frames of this piece that exist (idle lanes shadow the last row)
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 v[c].x = 2 * c < lim ? v[c].x : 0.0f;
@@ -635,9 +678,9 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         // the piece now lives in registers: hand the LDS buffer back to the DMA for piece k+1
         if (k < T && !HR_DBG(dbg, 16)) {
             const char *src = wave_base + (HR_DBG(dbg, 32) ? 0 : static_cast<size_t>(k + 1) * PB);  // dbg 32 (experiments): re-read piece 0 (cache hits)
-            if (fin_wave && k + 1 >= k_fin0) {
+            if (k + 1 >= k_fin) {
                 // piece k+1 of the final row reaches past the track: chunks that start beyond its end are not fetched
-                const int end_bytes = fin_valid * static_cast<int>(FB) - (k + 1) * static_cast<int>(PB);  // bytes of this piece that exist
+                const int end_bytes = fin_valid_now() * static_cast<int>(FB) - (k + 1) * static_cast<int>(PB);  // bytes of this piece that exist
 #pragma unroll
                 for (int j = 0; j < NDMA; j++) {
                     // (the DMA geometry above: which row and which source chunk this lane serves in instruction j)
@@ -663,7 +706,12 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
             }
         }
         // fragments of piece k go into slot k mod 3
-        make_frags(slot_c);
+        if (DO_TP && k >= k_fin) {  // (wave-uniform: the last steps of the wave that holds the track's last fused row)
+            make_frags(slot_c, std::true_type{}, lane >= last_row ? fin_keep_now() - 16 * k : 16);
+            refresh_bounds();                     // (the thresholds must see S_x before this step's tile is screened)
+        } else {
+            make_frags(slot_c, std::false_type{}, 16);
+        }
         if constexpr (!DO_TP) {
             if (dbg & 64) {
 #pragma unroll
@@ -847,7 +895,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         // columns of the signal fragments become zeros, so its outputs of these two tiles are exact zeros -- no bound, no
         // candidate.  (A lane's fragments of n-tile nt belong to wave row 32*nt + (lane & 31); the row's remaining
         // positions stay with the generic kernel.)
-        if (DO_TP && fin_wave && k >= T - 1) {
+        if (DO_TP && k > k_fin) {  // (tile k - 1 >= fin_keep / 16)
 #pragma unroll
             for (int nt = 0; nt < 2; nt++) {
                 const bool drop = 32 * nt + (lane & 31) >= last_row;
@@ -939,7 +987,7 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         run(k_split, T + 1, std::true_type{});
     }
 
-    if (DO_KW && lane < n_rows) {
+    if (DO_KW && lane < n_rows && h < t.n_hops) {  // (the ragged tail as a row, h == n_hops, is there for its peak only)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (k_short <= T) {
@@ -970,16 +1018,16 @@ __global__ void __launch_bounds__(256, 2) k_fused_f32s(const TrackDesc *__restri
         for (int c = 0; c < 2; c++) {
             Sf[c] = wave_max_f32(s_lane[c]);
             Af[c] = wave_max_f32(alb[c]);
-            lb[c] = fmaxf(lb[c], fmaxf(passthru0 ? Sf[c] : 0.0f, Af[c] - fmaf(kScreenRel, Sf[c], kScreenAbs)));
+            lb[c] = fmaxf(lb[c], fmaxf(passthru0 ? Sf[c] : 0.0f, Af[c] - fmaf(kScreenRel, fmaxf(Sf[c], S_x[c]), kScreenAbs)));
         }
         if (lane == 0) cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
         if (lane == 0 && n_rows > 0) {  // (padding waves list nothing and report nothing)
-            if (n_cand > kCandCap || Sf[0] >= kF16Safe || Sf[1] >= kF16Safe) overflow[it.track] = 1u;
+            if (n_cand > kCandCap || fmaxf(Sf[0], S_x[0]) >= kF16Safe || fmaxf(Sf[1], S_x[1]) >= kF16Safe) overflow[it.track] = 1u;
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 // non-negative floats order like their bit patterns
                 atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 0], __float_as_uint(lb[c]));
-                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(Sf[c]));
+                atomicMax(&tpb[(static_cast<size_t>(it.track) * kMaxCh + c) * 2 + 1], __float_as_uint(fmaxf(Sf[c], S_x[c])));
                 // phase-0 outputs are the samples themselves: exact, and not part of the screen
                 if (passthru0 && Sf[c] > 0.0f)
                     atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c],
@@ -1456,10 +1504,6 @@ static void launch_class(int tp_class, dim3 grid, dim3 block, size_t lds, hipStr
     k_fused_f32s<DO_KW, DO_TP, MT, SMALL, INF><<<grid, block, lds, st>>>(tracks, rates, items, n_items, recs, cands, \
                                                                           fs.cand_cnt, fs.tpb, fs.overflow, peaks, dbg)
 #ifdef HR_FAST_BUILD
-#ifndef HR_FAST_MT
-#define HR_FAST_MT 3
-#define HR_FAST_SMALL true
-#endif
     if constexpr (DO_KW && DO_TP && INF == 0) { HR_FUSED_CASE(HR_FAST_MT, HR_FAST_SMALL); }
     (void)tp_class;
 #else
@@ -1515,15 +1559,15 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
                        hipStream_t st)
 {
     if (!n_items) return;
-    const dim3 grid((n_items + 3) / 4), block(256);
+    const dim3 grid((n_items + kFusedWaves - 1) / kFusedWaves), block(64 * kFusedWaves);
     // (the data-movement-only ablation build takes just its piece buffers: more workgroups per CU, which shows how
     // the stream rate depends on the bytes in flight)
-    size_t lds = variant == 3 ? 4 * kPieceLds : kGroupLds;
+    size_t lds = variant == 3 ? kFusedWaves * kPieceLds : kGroupLds;
 #ifdef HR_EXPERIMENTS
     static const int lds_pad = std::getenv("HR_EXP_LDS_PAD") ? std::atoi(std::getenv("HR_EXP_LDS_PAD")) : 0;  // occupancy experiments
     lds += lds_pad;
     if (lds > 65536)
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_f32s<true, true, 3, true, 0>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_fused_f32s<true, true, HR_FAST_MT_OR_3, HR_FAST_SMALL_OR_TRUE, 0>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds));
 #endif
     uint2 *cands = static_cast<uint2 *>(fs.cands);

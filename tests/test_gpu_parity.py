@@ -658,3 +658,25 @@ def test_integer_stereo_is_read_directly_by_the_fused_kernel(oracle, meters, fs,
         assert g["integrated_lufs"] == w["integrated_lufs"] or (math.isnan(g["integrated_lufs"]) and math.isnan(w["integrated_lufs"]))
         if math.isfinite(ref["integrated_lufs"]):
             assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+
+
+@pytest.mark.parametrize("tp", ["swr192k", "bs1770"])
+@pytest.mark.parametrize("fs", [44100, 48000])
+@pytest.mark.parametrize("ragged", [0, 1, 7, 16, 21, 22, 40, 63, 64, 65, 100, 333, 1001, 3000])
+def test_largest_sample_near_the_end_of_the_track(oracle, meters, fs, ragged, tp):
+    """libswresample is not flushed: the last 16 positions produce no output, so a sample there is not a true peak
+    (BS.1770 bank: every position counts).  The track's end is where the fused kernel's final rows, the zeroed frames
+    and the generic tail kernel meet: the largest sample is put at several distances from the end, in and out of the
+    dropped zone, for ragged tails of every kind (none, shorter than a DMA chunk, odd, around the limits at which the
+    tail becomes a fused row)."""
+    hop = fs // 10
+    frames = 3 * hop + ragged
+    base = signals.seeded_noise(4242 + ragged, frames, 2, -40.0)
+    m = meters(tp=tp)
+    for dist, chan in [(1, 0), (5, 1), (16, 0), (17, 1), (18, 0), (33, 1), (49, 0), (ragged + 3, 1), (ragged + 40, 0), (hop + 5, 1)]:
+        if dist > frames:
+            continue
+        pcm = base.copy()
+        pcm[frames - dist, chan] = 0.9
+        pcm[frames - dist, 1 - chan] = -0.3
+        check_against_oracle(oracle, m, pcm, fs, tp=tp)
