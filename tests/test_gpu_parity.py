@@ -660,23 +660,50 @@ def test_integer_stereo_is_read_directly_by_the_fused_kernel(oracle, meters, fs,
             assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
 
 
-@pytest.mark.parametrize("tp", ["swr192k", "bs1770"])
-@pytest.mark.parametrize("fs", [44100, 48000])
-@pytest.mark.parametrize("ragged", [0, 1, 7, 16, 21, 22, 40, 63, 64, 65, 100, 333, 1001, 3000])
-def test_largest_sample_near_the_end_of_the_track(oracle, meters, fs, ragged, tp):
-    """libswresample is not flushed: the last 16 positions produce no output, so a sample there is not a true peak
-    (BS.1770 bank: every position counts).  The track's end is where the fused kernel's final rows, the zeroed frames
-    and the generic tail kernel meet: the largest sample is put at several distances from the end, in and out of the
-    dropped zone, for ragged tails of every kind (none, shorter than a DMA chunk, odd, around the limits at which the
-    tail becomes a fused row)."""
+END_RAGGED = [0, 1, 7, 16, 21, 22, 40, 63, 64, 65, 100, 333, 1001, 3000]
+
+
+def end_of_track_cases(oracle, m, fs, ragged, tp, kind):
     hop = fs // 10
     frames = 3 * hop + ragged
     base = signals.seeded_noise(4242 + ragged, frames, 2, -40.0)
-    m = meters(tp=tp)
     for dist, chan in [(1, 0), (5, 1), (16, 0), (17, 1), (18, 0), (33, 1), (49, 0), (ragged + 3, 1), (ragged + 40, 0), (hop + 5, 1)]:
         if dist > frames:
             continue
         pcm = base.copy()
         pcm[frames - dist, chan] = 0.9
         pcm[frames - dist, 1 - chan] = -0.3
-        check_against_oracle(oracle, m, pcm, fs, tp=tp)
+        if kind == "s16":
+            check_against_oracle(oracle, m, signals.to_s16(pcm), fs, tp=tp)
+        elif kind == "s24":
+            check_against_oracle(oracle, m, signals.to_s24_bytes(pcm), fs, tp=tp, channels=2, fmt=hr.FMT_S24)
+        else:
+            check_against_oracle(oracle, m, pcm, fs, tp=tp)
+
+
+@pytest.mark.parametrize("tp", ["swr192k", "bs1770"])
+@pytest.mark.parametrize("fs", [44100, 48000])
+@pytest.mark.parametrize("ragged", END_RAGGED)
+def test_largest_sample_near_the_end_of_the_track(oracle, meters, fs, ragged, tp):
+    """libswresample is not flushed: the last 16 positions produce no output, so a sample there is not a true peak
+    (BS.1770 bank: every position counts).  The track's end is where the fused kernel's final rows, the zeroed frames
+    and the generic tail kernel meet: the largest sample is put at several distances from the end, in and out of the
+    dropped zone, for ragged tails of every kind (none, shorter than a DMA chunk, odd, around the limits at which the
+    tail becomes a fused row)."""
+    end_of_track_cases(oracle, meters(tp=tp), fs, ragged, tp, "f32")
+
+
+@pytest.mark.parametrize("kind", ["s16", "s24"])
+@pytest.mark.parametrize("fs", [44100, 48000])
+@pytest.mark.parametrize("ragged", END_RAGGED)
+def test_largest_sample_near_the_end_of_an_integer_track(oracle, meters, fs, ragged, kind):
+    """The same for stereo s16 / s24 read directly by the fused kernel (four / eight frames per 16-byte chunk: other
+    alignment cases at the track's end)."""
+    end_of_track_cases(oracle, meters(tp="swr192k"), fs, ragged, "swr192k", kind)
+
+
+@pytest.mark.parametrize("fs", [88200, 96000, 32000, 8000])
+@pytest.mark.parametrize("ragged", [0, 23, 27, 28, 64, 501])
+def test_largest_sample_near_the_end_other_rates(oracle, meters, fs, ragged):
+    """Hops of other lengths (88.2 kHz: a row fetches 28 frames past its hop; 8 kHz: a hop is 50 pieces)."""
+    end_of_track_cases(oracle, meters(tp="swr192k"), fs, ragged, "swr192k", "f32")
