@@ -56,7 +56,7 @@ class HrShardPartial(C.Structure):
                 ("peak_per_ch", C.c_double * MAX_CH),
                 ("st_hist", C.c_uint64 * 8001), ("st_sum_kept", C.c_double), ("st_n_kept", C.c_uint64),
                 ("n_shortterm", C.c_uint64), ("max_m_power", C.c_double), ("max_s_power", C.c_double),
-                ("range_ok", C.c_int32), ("reserved", C.c_int32)]
+                ("range_ok", C.c_int32), ("reserved", C.c_int32), ("sum_gated", C.c_double), ("n_gated", C.c_uint64)]
 
 
 class HrTpTarget(C.Structure):
@@ -75,7 +75,7 @@ class HrPcmInfo(C.Structure):
 
 
 EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_free_pinned", "hr_analyze_batch",
-           "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_finish",
+           "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_pass3", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
            "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass", "hr_pcm_gain_file",
            "hr_analyze_device_noalloc", "hr_loudnorm_text_values", "hr_gain_decision_for_result"]
@@ -115,6 +115,7 @@ def lib():
     L.hr_shard_pass1.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
                                  C.c_int, C.c_uint64, C.POINTER(HrShardEdge)]
     L.hr_shard_pass2.argtypes = [C.c_void_p, C.POINTER(HrShardEdge), C.POINTER(HrShardPartial)]
+    L.hr_shard_pass3.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.POINTER(HrShardPartial)]
     L.hr_shard_finish.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.c_int, C.POINTER(HrResult)]
     L.hr_analyze_stream_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(HrTrack), C.POINTER(HrResult)]
     L.hr_pcm_probe.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(HrPcmInfo)]
@@ -236,6 +237,7 @@ class Meter:
         cfg = HrConfig(device, gate_mode, tp_mode, engine, stream, stage_bytes)
         _check(lib().hr_init(C.byref(cfg), C.byref(self._h)), "hr_init")
         self.device = device
+        self.gate_mode = gate_mode
 
     def close(self):
         if self._h:
@@ -353,6 +355,12 @@ class Meter:
         part = HrShardPartial()
         _check(lib().hr_shard_pass2(self._h, C.byref(left_edge) if left_edge is not None else None, C.byref(part)),
                "hr_shard_pass2")
+        return part
+
+    def shard_pass3(self, reduced):
+        """HR_GATE_EXACT: this shard's blocks above both gates, given the all-reduced sums of pass 2."""
+        part = HrShardPartial()
+        _check(lib().hr_shard_pass3(self._h, C.byref(reduced), C.byref(part)), "hr_shard_pass3")
         return part
 
     def shard_finish(self, partial, channels):

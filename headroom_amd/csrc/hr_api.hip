@@ -127,6 +127,7 @@ struct hr_ctx {
 
     // state of an open time shard (hr_shard_pass1 .. hr_shard_pass2)
     bool shard_open = false;
+    bool shard_pass2_done = false;  // HR_GATE_EXACT keeps the shard open from pass 2 to pass 3
     Group *shard_group = nullptr;
 
     bool no_alloc = false;  // inside hr_analyze_device_noalloc: workspace comes from the static scratch array, nothing is widened
@@ -1069,8 +1070,8 @@ try {
     if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->shard_open = false;  // (set again at the end, once the new shard's workspace is complete)
+    ctx->shard_pass2_done = false;
     HIPCHK(hipSetDevice(ctx->cfg.device));
-    if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
     const int v = validate_track(ctx, *shard);
     if (v) return v;
     const uint32_t hop = shard->sample_rate / 10;
@@ -1154,7 +1155,7 @@ int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *par
 try {
     if (!ctx || !partial) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!ctx->shard_open || !ctx->shard_group) return HR_ERR_INVALID;
+    if (!ctx->shard_open || ctx->shard_pass2_done || !ctx->shard_group) return HR_ERR_INVALID;
     HIPCHK(hipSetDevice(ctx->cfg.device));
     hipStream_t st = ctx->stream;
     Group &g = *ctx->shard_group;
@@ -1220,6 +1221,38 @@ try {
     }
     partial->n_shortterm = d.n_hops + d.st_pre >= 30 ? d.n_hops + d.st_pre - 29 : 0;
     partial->range_ok = range_ok ? 1 : 0;
+    ctx->shard_open = ctx->cfg.gate_mode == HR_GATE_EXACT;  // (its block powers are read once more: hr_shard_pass3)
+    ctx->shard_pass2_done = true;
+    return HR_OK;
+} HR_CATCH_ALL
+
+int hr_shard_pass3(hr_ctx *ctx, const hr_shard_partial *red, hr_shard_partial *partial)
+try {
+    if (!ctx || !red || !partial) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (ctx->cfg.gate_mode != HR_GATE_EXACT || !ctx->shard_open || !ctx->shard_pass2_done || !ctx->shard_group) return HR_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->stream;
+    Group &g = *ctx->shard_group;
+    // the shard's own track (descriptor 0) with the REDUCED abs-gated sums in its output slot: k_gate_final then takes
+    // the relative gate from them (n_parts == 0: "sums already reduced") and sums this shard's blocks above both gates
+    TrackDesc d = g.descs[0];
+    d.n_parts = 0;
+    TrackOut o{};
+    o.sum_kept = red->sum_kept;
+    o.n_kept = red->n_kept;
+    o.n_blocks = d.n_blocks;
+    HIPCHK(hipMemcpyAsync(ctx->tracks_d.p, &d, sizeof d, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(ctx->outs.p, &o, sizeof o, hipMemcpyHostToDevice, st));
+    launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, HR_GATE_EXACT, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
+                      ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(),
+                      ctx->ln_bounds.as<double>(), ctx->gate_parts.as<GatePart>(), false, ctx->outs.as<TrackOut>(), st);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    std::memset(partial, 0, sizeof *partial);
+    partial->sum_gated = o.sum_gated;
+    partial->n_gated = o.n_gated_final;
     ctx->shard_open = false;
     return HR_OK;
 } HR_CATCH_ALL
@@ -1230,7 +1263,6 @@ try {
     std::lock_guard<std::mutex> lk(ctx->mu);
     ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
-    if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
     hipStream_t st = ctx->stream;
     std::vector<uint32_t> hist(2 * kEbuBins);  // gating histogram, then the short-term one
     for (int i = 0; i < kEbuBins; i++) {
@@ -1252,6 +1284,18 @@ try {
     d.part_base = 0;
     d.n_parts = 1;
     TrackOut o{};
+    const bool exact = ctx->cfg.gate_mode == HR_GATE_EXACT;
+    if (exact) {  // both reductions are done: what k_gate_final's exact branch would leave (hr_kernels_generic.hip)
+        o.sum_kept = red->sum_kept;
+        o.n_kept = red->n_kept;
+        o.n_blocks = red->n_blocks;
+        if (red->n_kept) {
+            o.rel_energy = red->sum_kept / static_cast<double>(red->n_kept);
+            o.n_gated_final = red->n_gated;
+            o.sum_gated = red->sum_gated;
+            o.mean_energy = red->n_gated ? red->sum_gated / static_cast<double>(red->n_gated) : 0.0;
+        }
+    }
     int rc = upload(ctx->hist, hist.data(), kEbuBins * sizeof(uint32_t), st);
     if (!rc) rc = upload(ctx->st_hist, hist.data() + kEbuBins, kEbuBins * sizeof(uint32_t), st);
     if (!rc) rc = upload(ctx->gate_parts, &gp, sizeof gp, st);
@@ -1259,9 +1303,10 @@ try {
     if (!rc) rc = upload(ctx->tracks_d, &d, sizeof d, st);
     if (rc) return rc;
     if (!ctx->blk_powers.ensure(sizeof(double))) return HR_ERR_OOM;
-    launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(),
-                      ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(),
-                      ctx->ln_bounds.as<double>(), ctx->gate_parts.as<GatePart>(), false, ctx->outs.as<TrackOut>(), st);
+    if (!exact)
+        launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(),
+                          ctx->hist.as<uint32_t>(), ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(),
+                          ctx->ln_bounds.as<double>(), ctx->gate_parts.as<GatePart>(), false, ctx->outs.as<TrackOut>(), st);
     launch_range_stats(ctx->tracks_d.as<TrackDesc>(), 1, nullptr, 0, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(),
                        ctx->blk_powers.as<double>(), ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(),
                        ctx->ebu_edges.as<double>(), ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), true, ctx->outs.as<TrackOut>(), st);
@@ -1348,6 +1393,15 @@ try {
         red.max_m_power = std::max(red.max_m_power, part[r].max_m_power);
         red.max_s_power = std::max(red.max_s_power, part[r].max_s_power);
         red.range_ok = r == 0 ? part[r].range_ok : std::min(red.range_ok, part[r].range_ok);
+    }
+    if (ctxs[0]->cfg.gate_mode == HR_GATE_EXACT) {  // the second reduction: blocks above the relative gate the first one set
+        std::vector<hr_shard_partial> part3(active);
+        rc = on_all([&](int r) { return hr_shard_pass3(ctxs[r], &red, &part3[r]); });
+        if (rc) return rc;
+        for (int r = 0; r < active; r++) {
+            red.sum_gated += part3[r].sum_gated;
+            red.n_gated += part3[r].n_gated;
+        }
     }
     return hr_shard_finish(ctxs[0], &red, track->channels, out);
 } HR_CATCH_ALL

@@ -121,6 +121,7 @@ struct TrackOut {  // what the finalize kernel hands to the host
     double max_m_power, max_s_power;  // 0: no block
     uint64_t n_shortterm;
     int32_t lra_low_bin, lra_high_bin;  // histogram bins of the 10 % / 95 % points; -1: no block passed
+    double sum_gated;        // HR_GATE_EXACT: sum of the block powers in the final integration (mean_energy * n_gated_final)
 };
 
 }  // namespace hr

@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
         if (threadIdx.x == 0) {
             o.rel_energy = mean1;
             o.n_gated_final = nn;
+            o.sum_gated = ss;
             o.mean_energy = nn ? ss / static_cast<double>(nn) : 0.0;
         }
     }

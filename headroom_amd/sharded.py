@@ -16,7 +16,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import HrShardEdge, HrShardPartial, MAX_CH
+from . import GATE_EXACT, HrShardEdge, HrShardPartial, MAX_CH
 
 MIN_SHARD_HOPS = 6  # hr_shard_pass1: a shard hands the records of its last 6 hops to the right
 
@@ -147,6 +147,19 @@ def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels, first_
         lap("pass2")
     red = allreduce_partial(dist, part)
     lap("all_reduce")
+    if meter.gate_mode == GATE_EXACT:
+        # BS.1770's text has no histogram: the relative gate comes from the reduced sums, so the blocks above it are
+        # counted in a second pass over each shard's block powers and reduced once more (two numbers)
+        import torch
+        p3 = meter.shard_pass3(red) if shard_spec is not None and rank < active else HrShardPartial()
+        lap("pass3")
+        dev = _comm_device(dist)
+        ts = torch.tensor([p3.sum_gated], dtype=torch.float64, device=dev)
+        tn = torch.tensor([p3.n_gated], dtype=torch.int64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        dist.all_reduce(tn, op=dist.ReduceOp.SUM)
+        red.sum_gated, red.n_gated = float(ts.item()), int(tn.item())
+        lap("all_reduce")
     out = meter.shard_finish(red, channels)
     lap("finish")
     return out

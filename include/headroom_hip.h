@@ -155,7 +155,9 @@ int hr_block_energies(hr_ctx *ctx, const hr_track *track, double *hop_sums, uint
  * shard but the last holds a whole number of hops and at least 6 of them.  Each rank runs pass1
  * on its shard, hands its hr_shard_edge to the right neighbour, runs pass2 with the edge it got
  * from the left, and the hr_shard_partial records are all-reduced (sum; max for the peaks) before
- * hr_shard_finish.  HR_GATE_EXACT needs a second reduction and is not offered here.
+ * hr_shard_finish.  HR_GATE_EXACT has no histogram to reduce: its relative gate needs the all-reduced sums first, so
+ * there the ranks run hr_shard_pass3 with the reduced record, all-reduce (sum) its sum_gated / n_gated into the
+ * reduced record, and then call hr_shard_finish (two small all-reduces).
  * A context holds ONE open shard: pass 2 reads the workspace pass 1 left in the context, so any other call on that
  * context in between (hr_analyze_batch, hr_block_energies, hr_apply_gain, hr_loudnorm_first_pass, another pass 1, ...)
  * closes the shard and its hr_shard_pass2 then returns HR_ERR_INVALID.
@@ -186,6 +188,9 @@ typedef struct hr_shard_partial {
     double max_m_power, max_s_power; /* reduce with max */
     int32_t range_ok;                /* reduce with min: 0 when a shard was too short to hand its 29 hop energies on */
     int32_t reserved;
+    /* HR_GATE_EXACT only, written by hr_shard_pass3: this shard's blocks above both gates (reduce with sum) */
+    double sum_gated;
+    uint64_t n_gated;
 } hr_shard_partial;
 
 /* The first 16 frames of a shard as doubles, head[16][HR_MAX_CH]: what its left neighbour needs as
@@ -201,11 +206,14 @@ int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, 
 /* Phase 2: IIR carry hand-off from the left neighbour's edge (NULL for the first shard), the three
  * boundary blocks, and this shard's gating partial. */
 int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left_edge, hr_shard_partial *partial_out);
+/* HR_GATE_EXACT only (HR_ERR_INVALID in the other modes), between pass 2 and finish: `reduced` carries the all-reduced
+ * sum_kept / n_kept of pass 2, which set the relative gate (-10 LU below their mean); writes this shard's sum_gated /
+ * n_gated into partial_out (all its other fields zero).  The shard stays open from pass 2 until this call. */
+int hr_shard_pass3(hr_ctx *ctx, const hr_shard_partial *reduced, hr_shard_partial *partial_out);
 /* Gating from the all-reduced partial. */
 int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *reduced, int channels, hr_result *out);
 
-/* The same inside ONE process: n_ctx contexts (one per GPU; HR_GATE_EBUR128 or HR_GATE_LOUDNORM, same modes in
- * all of them) each take one time shard of `track`, the exchange steps above run on the host.  Host PCM, or
+/* The same inside ONE process: n_ctx contexts (one per GPU; same modes in all of them) each take one time shard of `track`, the exchange steps above run on the host.  Host PCM, or
  * device PCM when every context sits on the GPU that holds it.  Streams too short to cut (fewer than six
  * hops per shard) use fewer contexts.  No counterpart in the reference. */
 int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *track, hr_result *out);

@@ -136,6 +136,8 @@ pub mod sys {
         pub max_s_power: f64,
         pub range_ok: i32,
         pub reserved: i32,
+        pub sum_gated: f64,
+        pub n_gated: u64,
     }
 
     #[repr(C)]
@@ -187,6 +189,7 @@ pub mod sys {
         pub fn hr_shard_pass1(ctx: *mut hr_ctx, shard: *const hr_track, left_tail: *const f64, right_head: *const f64,
                               is_first: c_int, is_last: c_int, first_hop: u64, right_edge_out: *mut hr_shard_edge) -> c_int;
         pub fn hr_shard_pass2(ctx: *mut hr_ctx, left_edge: *const hr_shard_edge, partial_out: *mut hr_shard_partial) -> c_int;
+        pub fn hr_shard_pass3(ctx: *mut hr_ctx, reduced: *const hr_shard_partial, partial_out: *mut hr_shard_partial) -> c_int;
         pub fn hr_shard_finish(ctx: *mut hr_ctx, reduced: *const hr_shard_partial, channels: c_int, out: *mut hr_result) -> c_int;
         pub fn hr_analyze_stream_sharded(ctxs: *const *mut hr_ctx, n_ctx: c_int, track: *const hr_track, out: *mut hr_result) -> c_int;
         pub fn hr_synth_fill(ctx: *mut hr_ctx, device_pcm: *mut c_void, seed: u64, sample_rate: u32, channels: u32, frames: u64) -> c_int;

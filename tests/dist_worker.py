@@ -25,8 +25,9 @@ from headroom_amd import sharded  # noqa: E402
 class RecordingMeter:
     """Stand-in with the Meter's shard interface: computes nothing, records what the driver hands it."""
 
-    def __init__(self, rank):
+    def __init__(self, rank, gate_mode=hr.GATE_EBUR128):
         self.rank = rank
+        self.gate_mode = gate_mode
         self.seen = {}
 
     def _frames(self, spec, sl):
@@ -65,6 +66,13 @@ class RecordingMeter:
         p.max_m_power = 1.0 + self.rank
         p.max_s_power = 5.0 - self.rank
         p.range_ok = 0 if self.rank == 1 else 1
+        return p
+
+    def shard_pass3(self, red):
+        self.seen["reduced_for_pass3"] = (red.sum_kept, red.n_kept)
+        p = hr.HrShardPartial()
+        p.sum_gated = 0.125 * (self.rank + 1)
+        p.n_gated = 3 + self.rank
         return p
 
     def shard_finish(self, red, channels):
@@ -135,6 +143,14 @@ def mode_cpu(rank, world):
     assert red.n_shortterm == sum(50 + r for r in range(world))
     assert red.max_m_power == float(world) and red.max_s_power == 5.0 and red.range_ok == 0   # rank 1 vetoed
 
+    assert red.sum_gated == 0.0 and red.n_gated == 0 and "reduced_for_pass3" not in m.seen   # histogram modes: one reduction
+
+    # --- BS.1770's exact gating: a second pass sees the reduced sums, its two numbers are reduced once more ---------
+    mx = RecordingMeter(rank, hr.GATE_EXACT)
+    redx = sharded.analyze_stream_shard(dist, mx, spec, rank, world, 2, first_hop=cuts[rank] // 4800)
+    assert mx.seen["reduced_for_pass3"] == (sum(0.5 + r for r in range(world)), sum(10 + r for r in range(world)))
+    assert redx.sum_gated == sum(0.125 * (r + 1) for r in range(world)) and redx.n_gated == sum(3 + r for r in range(world))
+
     # --- a rank with an empty shard sits the passes out but joins the reduction --------------------
     m2 = RecordingMeter(rank)
     red2 = sharded.analyze_stream_shard(dist, m2, FakeSpec(pcm[:4800 * 7]) if rank == 0 else None, rank, 1, 2)
@@ -165,6 +181,15 @@ def mode_gpu(rank, world):
         assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
         for k in ("loudness_range_lu", "lra_low_lufs", "lra_high_lufs", "max_momentary_lufs", "max_shortterm_lufs"):
             assert abs(got[k] - whole[k]) < 1e-9, (k, got, whole)   # 83 hops over the ranks: every shard has its 32
+        # BS.1770's exact gating: two reductions (hr_shard_pass3 between them)
+        with hr.Meter(device=0, gate_mode=hr.GATE_EXACT) as mx:
+            got_x = sharded.analyze_stream_shard(dist, mx, spec, rank, world, 2, first_hop=cuts[rank] // 4800)
+            whole_x = mx.analyze(pcm, fs)
+            ref_x = oracle.measure(pcm, fs, gate_mode=1)
+            assert got_x["n_gated"] == whole_x["n_gated"] == ref_x["n_gated"], (got_x, whole_x)
+            assert abs(got_x["integrated_lufs"] - whole_x["integrated_lufs"]) < 1e-9
+            assert abs(got_x["integrated_lufs"] - ref_x["integrated_lufs"]) < 1e-6
+            assert got_x["peak_per_ch"] == ref_x["peak_per_ch"]
         # the same with the shard resident in HBM (device pointers, offset view for the tail)
         dev = torch.from_numpy(pcm[cuts[rank]:cuts[rank + 1]].copy()).cuda()
         got_d = sharded.analyze_stream_shard(dist, m, hr.TrackSpec(dev, fs), rank, world, 2, first_hop=cuts[rank] // 4800)

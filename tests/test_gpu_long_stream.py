@@ -12,7 +12,7 @@ import headroom_amd as hr
 
 pytestmark = pytest.mark.gpu
 
-GATES = {"ebur128": 0, "loudnorm": 2}
+GATES = {"ebur128": 0, "exact": 1, "loudnorm": 2}
 FS = 8000
 HOP = FS // 10
 CHUNK = 16384  # hr_device.hpp kGateChunk
@@ -55,7 +55,7 @@ def check_result(got, ref, rng_ref):
     assert got["loudness_range_lu"] > 5.0
 
 
-@pytest.mark.parametrize("gate", ["ebur128", "loudnorm"])
+@pytest.mark.parametrize("gate", ["ebur128", "loudnorm", "exact"])
 def test_many_gating_chunks_whole_and_sharded(oracle, stream, gate):
     ref = oracle.measure(stream, FS, gate_mode=GATES[gate], tp_mode=2)
     rng_ref = oracle.range_stats(stream, FS, GATES[gate])
@@ -95,6 +95,10 @@ def test_many_gating_chunks_whole_and_sharded(oracle, stream, gate):
             np.ctypeslib.as_array(red.st_hist)[:] = st_hist
             red.range_ok = min(p.range_ok for p in parts)
             assert red.range_ok == 1
+            if gate == "exact":
+                third = [mm.shard_pass3(red) for mm in ms]
+                red.sum_gated = sum(p.sum_gated for p in third)
+                red.n_gated = sum(p.n_gated for p in third)
             got = ms[0].shard_finish(red, 2)
         finally:
             for mm in ms:

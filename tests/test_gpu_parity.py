@@ -248,7 +248,7 @@ def test_time_shards_equal_whole_stream(oracle, meters):
     fs = 48000
     pcm = signals.seeded_noise(77, 4800 * 61 + 1000, 2, -17.0)
     pcm[: fs * 2] *= 0.002
-    for gate in ("ebur128", "loudnorm"):
+    for gate in ("ebur128", "loudnorm", "exact"):
         m = meters(gate)
         whole = m.analyze(pcm, fs)
         ref = oracle.measure(pcm, fs, gate_mode=GATES[gate])
@@ -281,6 +281,20 @@ def test_time_shards_equal_whole_stream(oracle, meters):
             red.max_m_power = max(red.max_m_power, p.max_m_power)
             red.max_s_power = max(red.max_s_power, p.max_s_power)
         red.range_ok = min(p.range_ok for p in partials)
+        if gate == "exact":
+            # BS.1770's text: no histogram, the relative gate needs the reduced sums first -> a second pass and reduction
+            assert all(p.hist[b] == 0 for p in partials for b in (0, 4000, 8000))
+            with pytest.raises(hr.HeadroomError):
+                m2[1].shard_pass2(edges[0])          # pass 2 twice
+            third = [mm.shard_pass3(red) for mm in m2]
+            red.sum_gated = sum(p.sum_gated for p in third)
+            red.n_gated = sum(p.n_gated for p in third)
+            with pytest.raises(hr.HeadroomError):
+                m2[0].shard_pass3(red)               # the shard is closed now
+        else:
+            with pytest.raises(hr.HeadroomError) as e:
+                m2[0].shard_pass3(red)               # the histogram modes have no third pass
+            assert e.value.code == hr.ERR_INVALID
         got = m2[0].shard_finish(red, 2)
         for mm in m2:
             mm.close()
@@ -402,7 +416,7 @@ def test_golden_vectors_on_gpu(meters, idx):
         assert [float.hex(float(x)) for x in got["peak_per_ch"]] == exp["peak_per_ch"], (key, got)
 
 
-@pytest.mark.parametrize("gate", ["ebur128", "loudnorm"])
+@pytest.mark.parametrize("gate", ["ebur128", "loudnorm", "exact"])
 def test_analyze_stream_sharded_in_process(oracle, meters, gate):
     """hr_analyze_stream_sharded: BASELINE config 5's shape in one process, here three contexts on one device
     (host PCM and device PCM), against the unsharded result and the oracle; short streams use fewer shards."""
