@@ -681,6 +681,22 @@ bool fused_s16(const hr_ctx *ctx, const hr_track &t, const void *dev)
     return has_tiles && (reinterpret_cast<uintptr_t>(dev) & 15) == 0;
 }
 
+// A track in device memory whose address keeps it off the fast kernels (stereo f32 needs 16-byte alignment for the
+// piece DMA, integer PCM 4-byte alignment for the plane split) is copied, device to device, into the group's staging
+// buffer like a host track: one extra read and write of its bytes instead of the generic f64 kernels, which are two
+// orders of magnitude slower per sample.
+bool restaged(const hr_ctx *ctx, const hr_track &t)
+{
+    if (!(t.flags & HR_TRACK_DEVICE_PCM) || ctx->no_alloc || ctx->cfg.engine == 1) return false;
+    const uint32_t hop = t.sample_rate / 10;
+    if (hop < 64 || t.frames / hop < 2 || hop * 8ull * 64 >= 0xffffffffull) return false;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(t.pcm);
+    if (t.fmt == HR_FMT_F32) return t.channels == 2 && (a & 15) != 0;
+    if (t.fmt == HR_FMT_S16 || t.fmt == HR_FMT_S24) return (a & 3) != 0;
+    return false;
+}
+bool on_device(const hr_ctx *ctx, const hr_track &t) { return (t.flags & HR_TRACK_DEVICE_PCM) && !restaged(ctx, t); }
+
 bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = nullptr)
 {
     const uint32_t hop = t.sample_rate / 10;
@@ -688,7 +704,7 @@ bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = null
     if (ctx->cfg.engine == 1 || hop < 64 || t.frames / hop < 2 || hop * 8ull * 64 >= 0xffffffffull) return false;
     if (t.fmt != HR_FMT_F32 && t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) return false;
     if (t.fmt == HR_FMT_F32 && t.channels == 2) return false;  // the fused kernel reads it as it is
-    const void *p = (t.flags & HR_TRACK_DEVICE_PCM) ? t.pcm : dev_or_null;  // staged copies are 256-byte aligned
+    const void *p = on_device(ctx, t) ? t.pcm : dev_or_null;  // staged copies are 256-byte aligned
     if (fused_s16(ctx, t, p)) return false;                     // likewise
     return (reinterpret_cast<uintptr_t>(p) & 3) == 0;
 }
@@ -744,7 +760,7 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     std::vector<size_t> off(idx.size(), 0);
     for (size_t k = 0; k < idx.size(); k++) {
         const hr_track &t = tracks[idx[k]];
-        if (t.flags & HR_TRACK_DEVICE_PCM) continue;
+        if (on_device(ctx, t)) continue;
         off[k] = stage_need;
         stage_need += (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
     }
@@ -759,10 +775,12 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     for (size_t k = 0; k < idx.size(); k++) {
         const hr_track &t = tracks[idx[k]];
         const void *dev = t.pcm;
-        if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
+        if (!on_device(ctx, t)) {
             dev = static_cast<char *>(ctx->stage.p) + off[k];
             const size_t bytes = t.frames * t.channels * fmt_bytes(t.fmt);
-            if (bytes) HIPCHK(hipMemcpyAsync(const_cast<void *>(dev), t.pcm, bytes, hipMemcpyHostToDevice, st));
+            if (bytes)
+                HIPCHK(hipMemcpyAsync(const_cast<void *>(dev), t.pcm, bytes,
+                                      (t.flags & HR_TRACK_DEVICE_PCM) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
         }
         desc_of[k] = add_track(ctx, g, t, dev, reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]), sp[k] != 0);
         if (desc_of[k] < 0) return desc_of[k];
@@ -913,7 +931,7 @@ try {
             out[i].max_momentary_lufs = out[i].max_shortterm_lufs = std::numeric_limits<double>::quiet_NaN();
         const int v = validate_track(ctx, tracks[i]);
         if (v) { out[i].status = v; continue; }
-        const size_t bytes = (tracks[i].flags & HR_TRACK_DEVICE_PCM)
+        const size_t bytes = on_device(ctx, tracks[i])
                                  ? 0 : tracks[i].frames * tracks[i].channels * fmt_bytes(tracks[i].fmt) + 256;
         const size_t wbytes = splits(ctx, tracks[i]) ? split_bytes(tracks[i]) : 0;
         if (!cur.empty() && (cur_bytes + bytes > ctx->cfg.stage_bytes || cur_widened + wbytes > widen_limit)) flush();

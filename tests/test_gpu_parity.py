@@ -721,3 +721,30 @@ def test_largest_sample_near_the_end_of_an_integer_track(oracle, meters, fs, rag
 def test_largest_sample_near_the_end_other_rates(oracle, meters, fs, ragged):
     """Hops of other lengths (88.2 kHz: a row fetches 28 frames past its hop; 8 kHz: a hop is 50 pieces)."""
     end_of_track_cases(oracle, meters(tp="swr192k"), fs, ragged, "swr192k", "f32")
+
+
+def test_misaligned_device_tracks_are_restaged(oracle, meters):
+    """Device PCM at an address the fast kernels cannot take (stereo f32 off the 16-byte grid, integer PCM off the dword
+    grid) is copied into the staging buffer instead of falling to the generic kernels: same numbers, and the fused
+    kernel's timer shows that it ran."""
+    import torch
+    fs = 44100
+    pcm = signals.seeded_noise(31, fs * 3 + 1235, 2, -14.0)
+    s16 = signals.to_s16(pcm)
+    s24 = signals.to_s24_bytes(pcm)
+    d32 = torch.from_numpy(np.concatenate([np.zeros((1, 2), np.float32), pcm])).cuda()         # + 8 bytes
+    d16 = torch.from_numpy(np.concatenate([np.zeros(1, np.int16), s16.reshape(-1)])).cuda()      # + 2 bytes
+    d24 = torch.from_numpy(np.concatenate([np.zeros(1, np.uint8), s24.reshape(-1)])).cuda()      # + 1 byte
+    specs = [hr.TrackSpec(d32.data_ptr() + 8, fs, channels=2, fmt=hr.FMT_F32, frames=len(pcm)),
+             hr.TrackSpec(d16.data_ptr() + 2, fs, channels=2, fmt=hr.FMT_S16, frames=len(pcm)),
+             hr.TrackSpec(d24.data_ptr() + 1, fs, channels=2, fmt=hr.FMT_S24, frames=len(pcm))]
+    refs = [oracle.measure(pcm, fs), oracle.measure(s16, fs), oracle.measure(s24, fs, channels=2, fmt=hr.FMT_S24)]
+    m = meters()
+    for spec, ref in zip(specs, refs):
+        got = m.analyze_batch([spec])[0]
+        assert got["status"] == 0 and got["n_gated"] == ref["n_gated"]
+        assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+        assert got["peak_per_ch"] == ref["peak_per_ch"]
+        assert m.last_timing()[1] > 0.0     # the fused kernel's own event pair
+    got = m.analyze_batch(specs + [hr.TrackSpec(pcm, fs)])
+    assert [g["peak_per_ch"] for g in got] == [r["peak_per_ch"] for r in refs + [refs[0]]]
