@@ -748,3 +748,44 @@ def test_misaligned_device_tracks_are_restaged(oracle, meters):
         assert m.last_timing()[1] > 0.0     # the fused kernel's own event pair
     got = m.analyze_batch(specs + [hr.TrackSpec(pcm, fs)])
     assert [g["peak_per_ch"] for g in got] == [r["peak_per_ch"] for r in refs + [refs[0]]]
+
+
+@pytest.mark.parametrize("layout", ["mono_f32", "5.1_f32", "5.1_s24", "3ch_s16"])
+@pytest.mark.parametrize("ragged", [0, 22, 65, 333, 1001])
+def test_largest_sample_near_the_end_of_a_track_measured_through_planes(oracle, meters, layout, ragged):
+    """Mono and multichannel tracks are split into stereo planes that take the fused kernel: the planes end like tracks."""
+    fs = 48000
+    ch = {"mono_f32": 1, "5.1_f32": 6, "5.1_s24": 6, "3ch_s16": 3}[layout]
+    frames = 3 * 4800 + ragged
+    base = signals.seeded_noise(999 + ragged + ch, frames, ch, -40.0)
+    m = meters()
+    for dist, chan in [(1, 0), (16, ch - 1), (17, 0), (40, ch - 1), (ragged + 20, 0)]:
+        pcm = base.copy()
+        pcm[frames - dist, chan] = 0.9
+        if layout.endswith("s24"):
+            check_against_oracle(oracle, m, signals.to_s24_bytes(pcm), fs, channels=ch, fmt=hr.FMT_S24)
+        elif layout.endswith("s16"):
+            check_against_oracle(oracle, m, signals.to_s16(pcm), fs)
+        else:
+            check_against_oracle(oracle, m, pcm, fs)
+
+
+@pytest.mark.parametrize("ragged", [0, 5, 64, 777])
+def test_largest_sample_near_the_end_of_a_sharded_stream(oracle, meters, ragged):
+    """The last time shard ends the stream: its final rows get the same care (the other shards end in a halo)."""
+    fs = 48000
+    frames = 4800 * 40 + ragged
+    base = signals.seeded_noise(555 + ragged, frames, 2, -35.0)
+    ms = [hr.Meter() for _ in range(3)]
+    try:
+        for dist in (1, 16, 17, 30, ragged + 5):
+            pcm = base.copy()
+            pcm[frames - dist, 0] = 0.9
+            pcm[4800 * 13 - 3, 1] = 0.8      # and one right in front of a cut (hr_analyze_stream_sharded cuts at hop 13 and 26)
+            ref = oracle.measure(pcm, fs)
+            got = hr.analyze_stream_sharded(ms, hr.TrackSpec(pcm, fs))
+            assert got["peak_per_ch"] == ref["peak_per_ch"], (dist, got, ref)
+            assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+    finally:
+        for mm in ms:
+            mm.close()

@@ -34,9 +34,6 @@ def main():
             m.close()
         worst = 0.0
         for (pcm, fs, kw, tag), g in zip(cases, got):
-            if tp == "swr192k" and fs == 11025:
-                assert g["status"] == hr.ERR_RATE, (seed, tag)
-                continue
             ref = oracle.measure(pcm, fs, gate_mode=GATES[gate], tp_mode=TPS[tp], **kw)
             ok = g["status"] == 0 and g["n_blocks"] == ref["n_blocks"] and g["n_gated"] == ref["n_gated"]
             if math.isfinite(ref["integrated_lufs"]):
