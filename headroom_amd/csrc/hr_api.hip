@@ -1440,7 +1440,13 @@ try {
     ctx->cfg.gate_mode = HR_GATE_LOUDNORM;
     ctx->cfg.tp_mode = HR_TP_SAMPLE;
     const double ninf = -std::numeric_limits<double>::infinity(), nan = std::numeric_limits<double>::quiet_NaN();
-    const size_t limit = 8ull << 30;  // resampled f64 PCM per group
+    // resampled f64 PCM per group: the more tracks share a launch of the one-thread-per-hop kernels the better they fill
+    // the GPU, so up to 32 GiB where a quarter of the free memory allows it (the buffer stays with the context)
+    size_t limit = 8ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) limit = std::min<size_t>(32ull << 30, std::max<size_t>(2ull << 30, free_b / 4));
+    }
     int fatal = HR_OK;
     size_t i = 0;
     while (i < n && !fatal) {

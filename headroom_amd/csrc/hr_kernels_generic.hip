@@ -754,10 +754,54 @@ __global__ void __launch_bounds__(256) k_resample_swr(const void *__restrict__ s
     }
 }
 
+// The exact-phase case (S == 1: every rate but the phase-interpolated ones) by tiles: a workgroup owns 256 consecutive
+// input positions, stages their window (with the reflections) in LDS once per channel, and its threads take the tile's
+// outputs in output order -- stores are coalesced, the phase arithmetic is 32-bit and relative to the tile, the 64-bit
+// division happens once per workgroup.  Same FMA order as above, so the same bits.
+template <int FMT>
+__global__ void __launch_bounds__(256) k_resample_swr_tiled(const void *__restrict__ src, int64_t N, int C, int P, int step,
+                                                            const double *__restrict__ taps, double *__restrict__ dst)
+{
+    __shared__ double xs[256 + kSwrTaps];
+    const int64_t p0 = static_cast<int64_t>(blockIdx.x) * 256;
+    const int np = N - p0 < 256 ? static_cast<int>(N - p0) : 256;
+    const int64_t n0 = swr_first_output(p0 * P, step, 1), n1 = swr_first_output((p0 + np) * P, step, 1);
+    const uint32_t r0 = static_cast<uint32_t>(n0 * step - p0 * P);  // < step
+    const uint32_t count = static_cast<uint32_t>(n1 - n0);
+    for (int c = 0; c < C; c++) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < np + kSwrTaps - 1; i += 256) {
+            int64_t k = p0 - 15 + i;
+            if (k < 0) k = -k;
+            if (k >= N) k = 2 * N - 1 - k;
+            xs[i] = (k < 0 || k >= N) ? 0.0 : ld_sample<FMT>(src, static_cast<uint64_t>(k) * C + c);
+        }
+        __syncthreads();
+        for (uint32_t m = threadIdx.x; m < count; m += 256) {
+            const uint32_t num = m * static_cast<uint32_t>(step) + r0;
+            const uint32_t pr = num / static_cast<uint32_t>(P), ph = num - pr * static_cast<uint32_t>(P);
+            const double *__restrict__ f = taps + static_cast<size_t>(ph) * kSwrTaps;
+            const double *x = xs + pr;
+            double val = 0.0;
+#pragma unroll
+            for (int i = 0; i < kSwrTaps; i++) val = fma(x[i], f[i], val);
+            dst[(n0 + m) * C + c] = val;
+        }
+    }
+}
+
 void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, int S, uint32_t frac_scale,
                          double inv_src_incr, const double *taps, double *dst, hipStream_t st)
 {
     if (!frames) return;
+    // (a tile's phase numerators stay below 256 * phases + step)
+    if (S == 1 && 256ull * static_cast<uint64_t>(phases) + static_cast<uint64_t>(step) < 0x7fffffffull && (frames + 255) / 256 < 0x7fffffffull) {
+        const dim3 grid(static_cast<uint32_t>((frames + 255) / 256));
+#define HR_RT_CASE(F) case F: k_resample_swr_tiled<F><<<grid, dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, taps, dst); break;
+        switch (fmt) { HR_RT_CASE(0) HR_RT_CASE(1) HR_RT_CASE(2) HR_RT_CASE(3) default: HR_RT_CASE(4) }
+#undef HR_RT_CASE
+        return;
+    }
     uint64_t blocks = (frames + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
 #define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, S, frac_scale, inv_src_incr, taps, dst); break;
