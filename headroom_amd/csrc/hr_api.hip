@@ -184,6 +184,10 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     std::memcpy(rd.G, rt->G, sizeof rd.G);
     std::memcpy(rd.M1, rt->M[0], sizeof rd.M1);
     std::memcpy(rd.M2, rt->M[1], sizeof rd.M2);
+    std::memcpy(rd.Gs, rt->sub_G, sizeof rd.Gs);
+    std::memcpy(rd.Ms, rt->sub_M, sizeof rd.Ms);
+    rd.sub_parts = static_cast<int32_t>(rt->sub_parts);
+    rd.sub_terms = rt->sub_terms;
     rd.hop = rt->hop;
     rd.q_n0 = rt->q_n0;
     std::memcpy(rd.q_ab, rt->q_ab, sizeof rd.q_ab);
@@ -260,6 +264,8 @@ void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bo
     d.frames = t.frames;
     d.fs = t.sample_rate;
     d.hop = t.sample_rate / 10;
+    d.row_len = d.hop;
+    d.parts = 1;
     d.n_hops = t.frames / d.hop;
     d.ch = t.channels;
     d.fmt = t.fmt;
@@ -293,7 +299,6 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     hipStream_t st = ctx->stream;
     const size_t nt = g.descs.size();
     if (!nt) return HR_OK;
-    if (!ctx->recs.ensure((g.rec_slots + 8) * sizeof(HopRec))) return HR_ERR_OOM;
     if (!ctx->hop_sums.ensure((g.hop_slots + 8) * sizeof(double))) return HR_ERR_OOM;
     if (!ctx->blk_powers.ensure(std::max<uint64_t>(g.blk_slots, 1) * sizeof(double))) return HR_ERR_OOM;
     if (!ctx->peaks.ensure(nt * kMaxCh * sizeof(unsigned long long))) return HR_ERR_OOM;
@@ -328,27 +333,97 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<uint8_t> ffin(nt, 0);
     std::vector<uint64_t> &fend = ctx->h_fend;  // fused tracks: first position the fused kernel does not screen
     fend.assign(nt, 0);
+    // Rows shorter than a hop (RateTables::sub_parts).  A wave costs its steps whatever the number of its lanes that hold a
+    // row, and a launch costs whole rounds of the GPU's 2048 wave slots: short tracks (100 hops are one full wave and one
+    // of 36 rows) and small batches (one 3-minute track is 29 waves) do better with rows of a third of a hop -- three
+    // times the rows, a third of the steps, at a few steps of fixed cost per row (the start of a row accumulates all
+    // four carry products; its last piece is partial).  Whole tracks whose last hop is a fused row only; never time shards.
+    const bool sub_ok = !ctx->split && !ctx->no_alloc && ctx->shard_group != &g && ctx->cfg.engine != 2;
+    std::vector<uint32_t> sub_p(nt, 1);
+    {
+        auto final_row_ok = [&](const TrackDesc &d, uint64_t rows, uint64_t len) {  // (see ffin below)
+            const uint32_t fb = fmt_bytes(d.fmt) * 2;
+            const uint64_t align = fb == 8 ? 2 : fb == 4 ? 4 : 8, T = (len + 15) / 16;
+            return d.stream_end && !d.right_head && (d.frames - (rows - 1) * len >= 16 * (T + 1) || d.frames % align == 0);
+        };
+        std::vector<uint64_t> w1(nt, 0), wP(nt, 0), t1(nt, 0), tP(nt, 0);  // waves of the track, steps of one of its waves
+        for (size_t i = 0; i < nt && sub_ok; i++) {
+            const TrackDesc &d = g.descs[i];
+            if (!fkw[i]) continue;
+            const RateDev &rd = ctx->rates_h[d.rate_idx];
+            t1[i] = (d.hop + 15) / 16 + 1;
+            w1[i] = (d.n_hops + 63) / 64;
+            const uint64_t P = static_cast<uint64_t>(rd.sub_parts);
+            const uint64_t len = P > 1 ? d.hop / P : d.hop;
+            const bool can = P > 1 && !d.left_tail && !d.right_head && d.blk_first == 0 && d.stream_start &&
+                             (len * fmt_bytes(d.fmt) * 2) % 16 == 0 && final_row_ok(d, d.n_hops * P, len);
+            tP[i] = can ? (len + 15) / 16 + 1 : t1[i];
+            wP[i] = can ? (d.n_hops * P + 63) / 64 : w1[i];
+        }
+        // What a launch costs, in steps: its waves run in rounds of the GPU's wave slots, a last partial round costs half
+        // a round plus its share (measured: profiles/README.md, round 2), one round or less costs one wave's steps.
+        auto estimate = [&](auto uses_sub) {
+            double waves = 0, steps = 0;
+            for (size_t i = 0; i < nt; i++) {
+                if (!w1[i]) continue;
+                const bool sub = uses_sub(i);
+                waves += static_cast<double>(sub ? wP[i] : w1[i]);
+                steps += static_cast<double>(sub ? wP[i] * tP[i] : w1[i] * t1[i]);
+            }
+            if (waves == 0) return 0.0;
+            const double rounds = waves / 2048.0, whole = std::floor(rounds), frac = rounds - whole;
+            const double eff = rounds <= 1.0 ? 1.0 : whole + (frac > 0 ? 0.5 + 0.5 * frac : 0.0);
+            return eff * steps / waves;
+        };
+        auto per_track = [&](size_t i) { return wP[i] * tP[i] * 100 < w1[i] * t1[i] * 97; };  // the track's own waves get fuller
+        auto all_sub = [&](size_t i) { return wP[i] != w1[i]; };
+        const double est_a = estimate([](size_t) { return false; }), est_b = estimate(per_track), est_c = estimate(all_sub);
+        int plan = 0;  // 0: whole hops; 1: shorter rows where a track's waves get fuller; 2: wherever a track allows them
+        if (ctx->cfg.engine == 3) plan = 2;
+        else if (est_c < 0.985 * est_a && est_c <= est_b) plan = 2;
+        else if (est_b < 0.985 * est_a) plan = 1;
+        for (size_t i = 0; i < nt && sub_ok; i++)
+            if (w1[i] && wP[i] != w1[i] && (plan == 2 || (plan == 1 && per_track(i)))) sub_p[i] = static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].sub_parts);
+    }
+    g.rec_slots = 0;
+    for (size_t i = 0; i < nt; i++) {
+        TrackDesc &d = g.descs[i];
+        d.parts = sub_p[i];
+        d.row_len = d.hop / d.parts;
+        d.rec_base = g.rec_slots;
+        g.rec_slots += (d.n_hops * d.parts + kPreRec) * d.ch;
+    }
+    if (!ctx->recs.ensure((g.rec_slots + 8) * sizeof(HopRec))) return HR_ERR_OOM;
     for (size_t i = 0; i < nt; i++) {
         TrackDesc &d = g.descs[i];
         d.fin_tail = 0;
         d.fin_valid = 0;
         if (!fkw[i]) continue;
-        const uint64_t last_hop0 = (d.n_hops - 1) * d.hop;
+        const uint64_t len = d.row_len, rows = d.n_hops * d.parts;
+        const uint64_t last_hop0 = (rows - 1) * len;  // (start of the last row that holds a whole hop's frames)
         fend[i] = last_hop0;
         if (!d.stream_end || d.right_head || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
         const uint64_t ragged = d.frames - d.n_hops * d.hop;
         const uint32_t fb = fmt_bytes(d.fmt) * 2;
-        const uint64_t T = (d.hop + 15) / 16;
+        const uint64_t T = (len + 15) / 16;
         const uint64_t align = fb == 8 ? 2 : fb == 4 ? 4 : 8;  // frames per 16 bytes of f32 / s16 / s24 stereo (s24: of 48)
         // (a row fetches pieces 0 .. T: 16 (T + 1) frames from its start)
         ffin[i] = d.frames - last_hop0 >= 16 * (T + 1) || d.frames % align == 0;
         if (!ffin[i]) continue;
+        // rows behind the last hop: the tail's whole rows (only when a row is less than a hop) and, if what is left is
+        // worth a lane, one partial row; all of them for their peak only
         const uint64_t usable = d.frames / align * align - d.n_hops * d.hop;  // (only meaningful when ragged >= align)
-        if (ftp[i] && ragged >= 64 && usable >= 48 && usable < d.hop) {
-            d.fin_tail = 1;
-            d.fin_valid = static_cast<uint32_t>(usable);
-            const uint64_t keep = usable > d.tp_drop ? usable - d.tp_drop : 0;
-            fend[i] = d.n_hops * d.hop + 16 * (keep / 16);
+        uint64_t tail_rows = 0;
+        if (ftp[i] && ragged >= 64 && usable >= 48) {
+            tail_rows = usable / len;
+            if (usable - tail_rows * len >= 48) tail_rows++;
+        }
+        if (tail_rows) {
+            d.fin_tail = static_cast<uint8_t>(tail_rows);
+            const uint64_t l0 = (rows + tail_rows - 1) * len;
+            d.fin_valid = static_cast<uint32_t>(d.n_hops * d.hop + usable - l0);
+            const uint64_t keep = d.fin_valid > d.tp_drop ? d.fin_valid - d.tp_drop : 0;
+            fend[i] = l0 + 16 * std::min<uint64_t>(keep / 16, T);
         } else {
             const uint64_t left = d.frames - last_hop0;
             d.fin_valid = static_cast<uint32_t>(std::min<uint64_t>(left, 1u << 30));
@@ -367,17 +442,19 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     constexpr int kFusedClasses = 20;
     size_t class_off[kFusedClasses + 1];
     // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
-    // mixes rates: every (class, rate) run is padded to a multiple of 4 with n_rows == 0 copies of its last item.
+    // mixes rates or row lengths: every (class, rate, row length) run is padded to a multiple of 4 with n_rows == 0
+    // copies of its last item.
     for (int cls = 0; cls < kFusedClasses; cls++) {
         class_off[cls] = fitems.size();
-        for (size_t ri = 0; ri < ctx->rates_h.size(); ri++) {
+        for (size_t rp = 0; rp < 2 * ctx->rates_h.size(); rp++) {  // (rate, whole-hop rows) then (rate, shorter rows)
+            const size_t ri = rp / 2;
             const size_t run_begin = fitems.size();
             for (size_t i = 0; i < nt; i++) {
-                if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri)) continue;
+                if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri) || (g.descs[i].parts > 1) != (rp % 2 == 1)) continue;
                 const RateDev &rd = ctx->rates_h[ri];
                 const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
-                const uint64_t interior = g.descs[i].n_hops - (ffin[i] ? 0 : 1) + g.descs[i].fin_tail;
+                const uint64_t interior = g.descs[i].n_hops * g.descs[i].parts - (ffin[i] ? 0 : 1) + g.descs[i].fin_tail;
                 for (uint64_t h = 0; h < interior; h += 64)
                     fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
             }
@@ -826,7 +903,7 @@ try {
     *out = nullptr;
     hr_config c{};
     if (cfg) c = *cfg;
-    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2) return HR_ERR_INVALID;
+    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 3) return HR_ERR_INVALID;
     const int n = hr_device_count();
     if (n <= 0) return HR_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;

@@ -35,6 +35,9 @@ struct RateDev {
     KCoef k;
     double G[16];
     double M1[16], M2[16];
+    // rows of hop / sub_parts frames (RateTables::sub_*): G and M over such a row, rows behind a row that set its start state
+    double Gs[16], Ms[16];
+    int32_t sub_parts, sub_terms;
     const double *g;         // [hop][4]
     const double *swr_taps;  // [(phases+1)][32] f64
     const void *tp_atab;     // f16 A fragments of the MFMA screen, [tp_np][tp_mt][3][64][8 halfs]; nullptr: no fused path
@@ -92,6 +95,9 @@ struct TrackDesc {
                            // be fetched (16-byte chunks that start inside them end inside the track)
     uint64_t first_hop;    // index of hop 0 in the whole stream (libebur128 takes its range blocks on a 1 s grid)
     uint32_t part_base, n_parts;  // gating chunks of kGateChunk blocks (one workgroup each): slots of their partial sums
+    // rows of the fused kernel: a hop is `parts` rows of row_len = hop / parts frames (1 and hop unless run_measure
+    // decides otherwise); zero-state records are per row: (row r, ch c) is rec_base + (kPreRec + r)*ch + c
+    uint32_t row_len, parts;
     float w[kMaxCh];
 };
 

@@ -69,7 +69,7 @@ typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 constexpr int kPieceLds = 8192, kCoefLds = 9 * 1024, kCarryLds = 1024;
 constexpr int kGroupLds = kFusedWaves * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
 constexpr int kFmtF32 = 0, kFmtS16 = 1, kFmtS24 = 2;  // HR_FMT_F32, HR_FMT_S16, HR_FMT_S24 of include/headroom_hip.h
-constexpr int kCandCap = 512;              // candidate slots per wave (k_refine_cands: one thread each)
+constexpr int kCandCap = 512;              // candidate slots per wave
 
 constexpr float kScreenRel = 4.1e-3f;  // >= (2^-10 [pkrtz x] + 2^-11 [rn h]) * L1(2.3522) + f32 accumulation
 constexpr float kScreenAbs = 4.0e-7f;  // f16 subnormal inputs / coefficients
@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     const RateDev &r = rates[t.rate_idx];
     const bool passthru0 = r.tp_passthru0 != 0;  // else (BS.1770 bank) the sample peak bounds nothing and phase 0 is screened
     const KCoef kc = r.k;
-    const uint32_t hop = t.hop;
+    const uint32_t hop = t.row_len;  // frames per row: a hop, or (TrackDesc::parts > 1) a whole fraction of one
     const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
     const int n_rows = static_cast<int>(it.n_rows);  // 0: a padding item (computes on row 0, reports nothing)
     const int last_row = n_rows > 0 ? n_rows - 1 : 0;
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     // row, the padding wave needs the same care -- it reads the same bytes)
     // One number stays live for all of this: k_fin, the first step that needs any care (the piece that holds frame
     // fin_keep; never, in every other wave).  The rare steps fetch the rest from the descriptor again.
-    const bool fin_wave = it.first_hop + static_cast<uint64_t>(last_row + 1) == t.n_hops + t.fin_tail;
+    const bool fin_wave = it.first_hop + static_cast<uint64_t>(last_row + 1) == t.n_hops * t.parts + t.fin_tail;
     const int k_fin = fin_wave ? (static_cast<int>(t.fin_valid) > t.tp_drop ? (static_cast<int>(t.fin_valid) - t.tp_drop) / 16 : 0) : (1 << 30);
     auto fin_valid_now = [&]() {
         const TrackDesc *tp = &t;
@@ -987,7 +987,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
         run(k_split, T + 1, std::true_type{});
     }
 
-    if (DO_KW && lane < n_rows && h < t.n_hops) {  // (the ragged tail as a row, h == n_hops, is there for its peak only)
+    if (DO_KW && lane < n_rows && h < t.n_hops * t.parts) {  // (the ragged tail as a row, behind the last hop, is there for its peak only)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (k_short <= T) {
@@ -1453,44 +1453,50 @@ __global__ void __launch_bounds__(PAIRS * 128, PAIRS == 2 ? 3 : 2) k_fused_split
 
 #endif  // HR_EXPERIMENTS (k_fused_split)
 
-// Exact evaluation of the candidates that can still be the maximum.  One workgroup per wave item of the
-// fused kernel, one thread per candidate slot.
-__global__ void __launch_bounds__(kCandCap) k_refine_cands(const TrackDesc *__restrict__ tracks,
-                                                          const RateDev *__restrict__ rates,
-                                                          const FusedItem *__restrict__ items,
-                                                          const uint2 *__restrict__ cands,
-                                                          const unsigned *__restrict__ cand_cnt,
-                                                          const unsigned *__restrict__ tpb,
-                                                          unsigned long long *__restrict__ peaks)
+// Exact evaluation of the candidates that can still be the maximum.  One wave per wave item of the fused kernel
+// (four items per workgroup), its lanes striding over the item's candidate list (a few dozen entries as a rule).
+__global__ void __launch_bounds__(256) k_refine_cands(const TrackDesc *__restrict__ tracks,
+                                                      const RateDev *__restrict__ rates,
+                                                      const FusedItem *__restrict__ items, uint32_t n_items,
+                                                      const uint2 *__restrict__ cands,
+                                                      const unsigned *__restrict__ cand_cnt,
+                                                      const unsigned *__restrict__ tpb,
+                                                      unsigned long long *__restrict__ peaks)
 {
-    const unsigned n = cand_cnt[blockIdx.x];
-    if (threadIdx.x >= n) return;
-    const FusedItem it = items[blockIdx.x];
+    const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (item >= n_items) return;
+    const unsigned n = cand_cnt[item];
+    const int lane = threadIdx.x & 63;
+    if (static_cast<unsigned>(lane) >= n) return;
+    const FusedItem it = items[item];
     const TrackDesc &t = tracks[it.track];
     const RateDev &r = rates[t.rate_idx];
-    const uint2 e = cands[static_cast<size_t>(blockIdx.x) * kCandCap + threadIdx.x];
-    const int ch = e.x & 1u, crow = (e.x >> 1) & 63u, mt = (e.x >> 7) & 3u, half = (e.x >> 9) & 1u;
-    const int tile = static_cast<int>(e.x >> 10);
-    const float lbf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 0]);
-    const float Sf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 1]);
-    const float err = fmaf(kScreenRel, Sf, kScreenAbs);  // >= the bound that held when the group was screened
-    if (__uint_as_float(e.y) + err < lbf) return;        // cannot reach the track's proven lower bound
     const int P = r.swr_phases, step = r.swr_step;
-    const long num0 = 16L * tile * P, num1 = 16L * (tile + 1) * P;
-    const int m_lo = static_cast<int>((num0 + step - 1) / step);
-    const int count = static_cast<int>((num1 + step - 1) / step) - m_lo;
-    const int64_t row_frame0 = static_cast<int64_t>(it.first_hop + crow) * t.hop;
-    double best = 0.0;
-    for (int i = 0; i < 16; i++) {
-        const int rowidx = 32 * mt + 4 * half + (i & 3) + 8 * (i >> 2);
-        if (rowidx >= count) continue;
-        const int m = m_lo + rowidx;
-        if (r.tp_passthru0 && (m * step) % P == 0) continue;  // pass-through phase: taken exactly from the sample peak
-        const double a = exact_output(t, r.swr_taps, P, step, row_frame0, ch, m);
-        best = a > best ? a : best;
+    double best0 = 0.0, best1 = 0.0;
+    for (unsigned ci = lane; ci < n; ci += 64) {
+        const uint2 e = cands[static_cast<size_t>(item) * kCandCap + ci];
+        const int ch = e.x & 1u, crow = (e.x >> 1) & 63u, mt = (e.x >> 7) & 3u, half = (e.x >> 9) & 1u;
+        const int tile = static_cast<int>(e.x >> 10);
+        const float lbf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 0]);
+        const float Sf = __uint_as_float(tpb[(static_cast<size_t>(it.track) * kMaxCh + ch) * 2 + 1]);
+        const float err = fmaf(kScreenRel, Sf, kScreenAbs);  // >= the bound that held when the group was screened
+        if (__uint_as_float(e.y) + err < lbf) continue;      // cannot reach the track's proven lower bound
+        const long num0 = 16L * tile * P, num1 = 16L * (tile + 1) * P;
+        const int m_lo = static_cast<int>((num0 + step - 1) / step);
+        const int count = static_cast<int>((num1 + step - 1) / step) - m_lo;
+        const int64_t row_frame0 = static_cast<int64_t>(it.first_hop + crow) * t.row_len;
+        for (int i = 0; i < 16; i++) {
+            const int rowidx = 32 * mt + 4 * half + (i & 3) + 8 * (i >> 2);
+            if (rowidx >= count) continue;
+            const int m = m_lo + rowidx;
+            if (r.tp_passthru0 && (m * step) % P == 0) continue;  // pass-through phase: taken exactly from the sample peak
+            const double a = exact_output(t, r.swr_taps, P, step, row_frame0, ch, m);
+            if (ch) best1 = a > best1 ? a : best1;
+            else best0 = a > best0 ? a : best0;
+        }
     }
-    if (best > 0.0)
-        atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + ch], static_cast<unsigned long long>(__double_as_longlong(best)));
+    if (best0 > 0.0) atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + 0], static_cast<unsigned long long>(__double_as_longlong(best0)));
+    if (best1 > 0.0) atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + 1], static_cast<unsigned long long>(__double_as_longlong(best1)));
 }
 
 size_t fused_cand_bytes(uint32_t n_items) { return static_cast<size_t>(n_items) * kCandCap * sizeof(uint2); }
@@ -1581,14 +1587,14 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
         case 4: launch_split_case<3, false>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
         default: launch_split_case<3, true>(grid, st, tracks, rates, items, recs, cands, fs, peaks); break;
         }
-        k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
+        k_refine_cands<<<dim3((n_items + 3) / 4), dim3(256), 0, st>>>(tracks, rates, items, n_items, cands, fs.cand_cnt, fs.tpb, peaks);
         return;
     }
 #endif
     if (variant == 5 || variant == 6) {  // full pass on stereo s16 / s24
         if (variant == 5) launch_class<true, true, 1>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
         else launch_class<true, true, 2>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg);
-        k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
+        k_refine_cands<<<dim3((n_items + 3) / 4), dim3(256), 0, st>>>(tracks, rates, items, n_items, cands, fs.cand_cnt, fs.tpb, peaks);
         return;
     }
     switch (variant) {
@@ -1598,7 +1604,7 @@ void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const Fuse
     default: launch_class<true, true>(tp_class, grid, block, lds, st, tracks, rates, items, n_items, recs, cands, fs, peaks, dbg); break;
     }
     if (variant == 0 || variant == 2)
-        k_refine_cands<<<dim3(n_items), dim3(kCandCap), 0, st>>>(tracks, rates, items, cands, fs.cand_cnt, fs.tpb, peaks);
+        k_refine_cands<<<dim3((n_items + 3) / 4), dim3(256), 0, st>>>(tracks, rates, items, n_items, cands, fs.cand_cnt, fs.tpb, peaks);
 }
 
 }  // namespace hr

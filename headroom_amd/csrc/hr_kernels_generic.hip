@@ -180,6 +180,56 @@ __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict
     const RateDev &r = rates[t.rate_idx];
 
     const HopRec *base = recs + t.rec_base + kPreRec * C + c;  // hop 0, channel c; stride C
+    if (t.parts > 1) {
+        // The hop is `parts` rows, each filtered from zero state (whole tracks only: nothing in front of row 0).  State at the
+        // first row's start: the end states of the sub_terms rows before it, by Horner; at the next rows' starts by the exact
+        // recurrence s' = Ms s + zend.  The hop's energy is the sum of its rows'.
+        const int P = static_cast<int>(t.parts), K = r.sub_terms;
+        const int64_t r0 = h * P;
+        double s[4] = {0, 0, 0, 0};
+        for (int k = K; k >= 1; k--) {
+            const int64_t rr = r0 - k;
+            if (rr < 0) continue;  // (s is still zero)
+            const double *z = base[rr * C].s;
+            double n[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double a = z[i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
+                n[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[i] = n[i];
+        }
+        double H = 0;
+        for (int p = 0; p < P; p++) {
+            const HopRec &row = base[(r0 + p) * C];
+            double lin = 0, quad = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lin = fma(s[i], row.q[i], lin);
+                double gs = 0;
+#pragma unroll
+                for (int j = 0; j < 4; j++) gs = fma(r.Gs[i * 4 + j], s[j], gs);
+                quad = fma(s[i], gs, quad);
+            }
+            H += row.e0 + (2.0 * lin + quad);
+            double n[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double a = row.s[i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
+                n[i] = a;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) s[i] = n[i];
+        }
+        if (H < 0) H = 0;
+        hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;
+        return;
+    }
     const HopRec &me = base[h * C];
     // records in front of hop 0 exist only for a shard with a left neighbour (blk_first < 0)
     const bool edge = t.blk_first < 0;

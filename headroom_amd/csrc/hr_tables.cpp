@@ -269,6 +269,7 @@ static void build_carry(RateTables &rt)
     long double r = 0;
     for (int i = 0; i < 16; i++) r = std::fmax(r, std::fabs(Mp[i]));
     rt.carry_residual = static_cast<double>(r);
+    rt.gl_keep = gl;  // (build_sub_rows, once the resampler's step is known)
 
     // q truncation point: fit g_j (j = 0, 1) on [n0, L) by the two RLB free modes g_2, g_3 (2x2 normal
     // equations in long double) and take the first multiple of 48 (three 16-frame steps of the fused kernel) where the mismatch is below 1e-15.
@@ -306,6 +307,55 @@ static void build_carry(RateTables &rt)
     }
 }
 
+// Rows of hop / p frames (RateTables::sub_parts): the smallest p >= 2 whose rows are at most 1600 frames, even (16-byte
+// rows of stereo f32), whole multiples of the resampler's input step (every row starts at phase 0 of both banks; the
+// BS.1770 bank's step is 1), and long enough for the q truncation and a few steps behind it.
+static void build_sub_rows(RateTables &rt)
+{
+    const std::vector<long double> gl = std::move(rt.gl_keep);
+    rt.gl_keep.clear();
+    const uint32_t step = rt.swr_S == 1 && rt.swr_phases > 0 ? static_cast<uint32_t>(rt.swr_step) : 1u;
+    for (uint32_t p = 2; p <= 16; p++) {
+        if (rt.hop % p) continue;
+        const uint32_t len = rt.hop / p;
+        if (len > 1600) continue;
+        if (len % 2 || len % step || len < 512 || len < rt.q_n0 + 96) break;  // (shorter rows only get worse)
+        long double G[16] = {0}, M[16], Mp[16], Mn[16];
+        for (uint32_t n = 0; n < len; n++)
+            for (int a = 0; a < 4; a++)
+                for (int b = 0; b < 4; b++) G[a * 4 + b] += gl[static_cast<size_t>(n) * 4 + a] * gl[static_cast<size_t>(n) * 4 + b];
+        // the state after len frames of the zero-input response to unit component j: the cascade again, to len
+        const KCoef &k = rt.k;
+        for (int j = 0; j < 4; j++) {
+            long double y1 = j == 0, y2 = (j == 0) - (j == 1), z1 = j == 2, z2 = (j == 2) - (j == 3);
+            for (uint32_t n = 0; n < len; n++) {
+                const long double y0 = -static_cast<long double>(k.pa1) * y1 - static_cast<long double>(k.pa2) * y2;
+                const long double z0 = (y0 - 2.0L * y1 + y2) - static_cast<long double>(k.ra1) * z1 - static_cast<long double>(k.ra2) * z2;
+                y2 = y1; y1 = y0;
+                z2 = z1; z1 = z0;
+            }
+            M[0 * 4 + j] = y1; M[1 * 4 + j] = y1 - y2; M[2 * 4 + j] = z1; M[3 * 4 + j] = z1 - z2;
+        }
+        for (int i = 0; i < 16; i++) Mp[i] = M[i];
+        int terms = 1;
+        long double res = 1;
+        for (; terms < 64; terms++) {  // Mp = M^terms
+            res = 0;
+            for (int i = 0; i < 16; i++) res = std::fmax(res, std::fabs(Mp[i]));
+            if (res < 1e-20L) break;
+            matmul4(Mp, M, Mn);
+            for (int i = 0; i < 16; i++) Mp[i] = Mn[i];
+        }
+        if (res >= 1e-20L) break;
+        rt.sub_parts = p;
+        rt.sub_len = len;
+        rt.sub_terms = terms;
+        rt.sub_residual = static_cast<double>(res);
+        for (int i = 0; i < 16; i++) { rt.sub_G[i] = static_cast<double>(G[i]); rt.sub_M[i] = static_cast<double>(M[i]); }
+        return;
+    }
+}
+
 const RateTables *rate_tables(uint32_t fs)
 {
     static std::mutex mu;
@@ -320,6 +370,7 @@ const RateTables *rate_tables(uint32_t fs)
     rt->k = kweight_coeffs(static_cast<double>(fs));
     build_carry(*rt);
     build_swr(*rt);
+    build_sub_rows(*rt);
     // (the sample peak stands in for phase 0 only where EVERY input frame is a phase-0 output, i.e. at integer ratios:
     // at 44.1 kHz only every 147th frame is one, and an isolated peak between two of them is not an output at all)
     // (phase-interpolated rates -- swr_S > 1 -- have no tile table: their true peak runs on the generic kernel)

@@ -30,6 +30,16 @@ struct RateTables {
     double G[16];            // sum_n g[n][j]*g[n][k]
     double M[kCarryTerms - 1][16];  // M^1, M^2 (row-major): state transfer over one hop
     double carry_residual = 0;      // |M^kCarryTerms|_max, must be negligible
+    // Rows shorter than a hop (hr_kernels_fused.hip: short tracks and small batches fill more lanes, and finish sooner,
+    // when a hop is sub_parts rows of sub_len = hop / sub_parts frames; 1: this rate has no such division).  A row still
+    // starts where the resampler's phase pattern starts (sub_len is a multiple of swr_step) and on a 16-byte boundary of
+    // stereo f32.  sub_G / sub_M: G and M over sub_len frames; the state at a row's start needs the end states of the
+    // sub_terms rows before it (|sub_M^sub_terms|_max = sub_residual, negligible).
+    std::vector<long double> gl_keep;  // (scratch of the builder)
+    uint32_t sub_parts = 1, sub_len = 0;
+    double sub_G[16] = {0}, sub_M[16] = {0};
+    int sub_terms = 0;
+    double sub_residual = 0;
     // Once the pre-filter's own transient has died (n >= q_n0, a multiple of 48), the responses to the two
     // pre-filter state components are free modes of the RLB stage, i.e. combinations of g[.][2], g[.][3]:
     //   g[n][j] = q_ab[j][0]*g[n][2] + q_ab[j][1]*g[n][3]   (j = 0, 1; n >= q_n0)

@@ -50,7 +50,7 @@ def check_against_oracle(oracle, m, pcm, fs, gate="ebur128", tp="swr192k", **kw)
     return got, ref
 
 
-@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("engine", [0, 1, 2, 3])  # (2 / 3: rows of a whole hop only / of a fraction of a hop)
 @pytest.mark.parametrize("fs", [44100, 48000, 96000])
 def test_block_energies_match_oracle(oracle, meters, fs, engine):
     pcm = signals.seeded_noise(100 + fs, fs * 5 + 1234, 2, -18.0)
@@ -64,7 +64,7 @@ def test_block_energies_match_oracle(oracle, meters, fs, engine):
     assert np.max(np.abs(P / Pref - 1)) < 1e-9
 
 
-@pytest.mark.parametrize("engine", [0, 1])
+@pytest.mark.parametrize("engine", [0, 1, 2, 3])
 @pytest.mark.parametrize("gate", ["ebur128", "exact", "loudnorm"])
 @pytest.mark.parametrize("fs", [44100, 48000, 96000])
 def test_measure_noise(oracle, meters, fs, gate, engine):
@@ -383,11 +383,11 @@ def test_low_frequency_content_carry_terms(oracle, meters, fs):
     t = np.arange(n) / fs
     pcm = np.stack([0.4 * np.sin(2 * np.pi * 25.0 * t) + 0.3, 0.2 * np.cos(2 * np.pi * 31.0 * t) - 0.25], axis=1).astype(np.float32)
     pcm += signals.seeded_noise(5, n, 2, -60.0)
-    for engine in (0, 1):
+    for engine in (0, 1, 2, 3):
         H, P = meters(engine=engine).block_energies(hr.TrackSpec(pcm, fs))
         Href = oracle.hop_sums(pcm, fs)
         assert np.max(np.abs(H / Href - 1)) < 1e-9
-    check_against_oracle(oracle, meters(), pcm, fs)
+        check_against_oracle(oracle, meters(engine=engine), pcm, fs)
 
 
 @pytest.mark.parametrize("idx", range(10))
@@ -695,16 +695,17 @@ def end_of_track_cases(oracle, m, fs, ragged, tp, kind):
             check_against_oracle(oracle, m, pcm, fs, tp=tp)
 
 
+@pytest.mark.parametrize("engine", [2, 3])
 @pytest.mark.parametrize("tp", ["swr192k", "bs1770"])
 @pytest.mark.parametrize("fs", [44100, 48000])
 @pytest.mark.parametrize("ragged", END_RAGGED)
-def test_largest_sample_near_the_end_of_the_track(oracle, meters, fs, ragged, tp):
+def test_largest_sample_near_the_end_of_the_track(oracle, meters, fs, ragged, tp, engine):
     """libswresample is not flushed: the last 16 positions produce no output, so a sample there is not a true peak
     (BS.1770 bank: every position counts).  The track's end is where the fused kernel's final rows, the zeroed frames
     and the generic tail kernel meet: the largest sample is put at several distances from the end, in and out of the
     dropped zone, for ragged tails of every kind (none, shorter than a DMA chunk, odd, around the limits at which the
     tail becomes a fused row)."""
-    end_of_track_cases(oracle, meters(tp=tp), fs, ragged, tp, "f32")
+    end_of_track_cases(oracle, meters(tp=tp, engine=engine), fs, ragged, tp, "f32")
 
 
 @pytest.mark.parametrize("kind", ["s16", "s24"])
