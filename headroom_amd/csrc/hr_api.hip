@@ -379,8 +379,12 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         auto all_sub = [&](size_t i) { return wP[i] != w1[i]; };
         const double est_a = estimate([](size_t) { return false; }), est_b = estimate(per_track), est_c = estimate(all_sub);
         int plan = 0;  // 0: whole hops; 1: shorter rows where a track's waves get fuller; 2: wherever a track allows them
+        // (measured: over several rounds shorter rows everywhere gain nothing -- 1000 three-minute tracks 19.8 against
+        // 19.65 ms, and their combine kernel costs 0.4 ms more -- so plan 2 is for launches of at most one round)
+        double waves_a = 0;
+        for (size_t i = 0; i < nt; i++) waves_a += static_cast<double>(w1[i]);
         if (ctx->cfg.engine == 3) plan = 2;
-        else if (est_c < 0.985 * est_a && est_c <= est_b) plan = 2;
+        else if (waves_a <= 2048.0 && est_c < 0.985 * est_a && est_c <= est_b) plan = 2;
         else if (est_b < 0.985 * est_a) plan = 1;
         for (size_t i = 0; i < nt && sub_ok; i++)
             if (w1[i] && wP[i] != w1[i] && (plan == 2 || (plan == 1 && per_track(i)))) sub_p[i] = static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].sub_parts);
@@ -591,7 +595,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     ctx->comb_n = comb_span.n;
     if (do_combine)
         launch_hop_combine(dt, dr, di + comb_span.off, static_cast<uint32_t>(comb_span.n), ctx->recs.as<HopRec>(),
-                           ctx->hop_sums.as<double>(), st);
+                           ctx->hop_sums.as<double>(), std::any_of(sub_p.begin(), sub_p.end(), [](uint32_t p) { return p > 1; }), st);
     if (do_combine && !g.parents.empty()) {
         rc = upload(ctx->parents_d, g.parents.data(), g.parents.size() * sizeof(uint32_t), st);
         if (rc) return rc;
@@ -1284,7 +1288,7 @@ try {
     int rc = upload(ctx->tracks_d, g.descs.data(), g.descs.size() * sizeof(TrackDesc), st);  // (st_pre may have changed)
     if (rc) return rc;
     launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->items_d.as<WorkItem>() + ctx->comb_off,
-                       static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), st);
+                       static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), false, st);
     rc = run_gating(ctx, g, false, true);
     if (rc) return rc;
     rc = redo_overflowed_peaks(ctx, g);

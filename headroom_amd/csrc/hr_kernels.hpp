@@ -14,7 +14,7 @@ void launch_hop_zero_state(int fmt, const TrackDesc *tracks, const RateDev *rate
 void launch_hop_zero_state_list(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items,
                                 uint32_t n_items, HopRec *recs, hipStream_t st);
 void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
-                        const HopRec *recs, double *hop_sums, hipStream_t st);
+                        const HopRec *recs, double *hop_sums, bool any_rows, hipStream_t st);
 // ebu_edges: hr_tables.hpp ebur128_bin_edges() on the device (3 x kEbuBins powers): f_ebur128.c's bin decisions without a
 // device logarithm.
 // Gating runs in chunks of kGateChunk blocks, one workgroup each (items: track, pad = chunk index, first = first block);

@@ -180,63 +180,17 @@ __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict
     const RateDev &r = rates[t.rate_idx];
 
     const HopRec *base = recs + t.rec_base + kPreRec * C + c;  // hop 0, channel c; stride C
-    if (t.parts > 1) {
-        // The hop is `parts` rows, each filtered from zero state (whole tracks only: nothing in front of row 0).  State at the
-        // first row's start: the end states of the sub_terms rows before it, by Horner; at the next rows' starts by the exact
-        // recurrence s' = Ms s + zend.  The hop's energy is the sum of its rows'.
-        const int P = static_cast<int>(t.parts), K = r.sub_terms;
-        const int64_t r0 = h * P;
-        double s[4] = {0, 0, 0, 0};
-        for (int k = K; k >= 1; k--) {
-            const int64_t rr = r0 - k;
-            if (rr < 0) continue;  // (s is still zero)
-            const double *z = base[rr * C].s;
-            double n[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double a = z[i];
-#pragma unroll
-                for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
-                n[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) s[i] = n[i];
-        }
-        double H = 0;
-        for (int p = 0; p < P; p++) {
-            const HopRec &row = base[(r0 + p) * C];
-            double lin = 0, quad = 0;
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                lin = fma(s[i], row.q[i], lin);
-                double gs = 0;
-#pragma unroll
-                for (int j = 0; j < 4; j++) gs = fma(r.Gs[i * 4 + j], s[j], gs);
-                quad = fma(s[i], gs, quad);
-            }
-            H += row.e0 + (2.0 * lin + quad);
-            double n[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                double a = row.s[i];
-#pragma unroll
-                for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
-                n[i] = a;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) s[i] = n[i];
-        }
-        if (H < 0) H = 0;
-        hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;
-        return;
-    }
+    if (t.parts > 1) return;  // (k_hop_combine_rows)
     const HopRec &me = base[h * C];
     // records in front of hop 0 exist only for a shard with a left neighbour (blk_first < 0)
     const bool edge = t.blk_first < 0;
-    const double zero4[4] = {0, 0, 0, 0};
-    const double *p1 = (h - 1 >= 0 || edge) ? base[(h - 1) * C].s : zero4;
-    const double *p2 = (h - 2 >= 0 || edge) ? base[(h - 2) * C].s : zero4;
-    const double *p3 = (h - 3 >= 0 || edge) ? base[(h - 3) * C].s : zero4;
+    double p1[4], p2[4], p3[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        p1[i] = (h - 1 >= 0 || edge) ? base[(h - 1) * C].s[i] : 0.0;
+        p2[i] = (h - 2 >= 0 || edge) ? base[(h - 2) * C].s[i] : 0.0;
+        p3[i] = (h - 3 >= 0 || edge) ? base[(h - 3) * C].s[i] : 0.0;
+    }
     double s[4];
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -258,6 +212,71 @@ __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict
     }
     double H = me.e0 + (2.0 * lin + quad);
     if (H < 0) H = 0;  // cancellation on (near-)DC input can leave a tiny negative
+    hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;
+}
+
+// The same for tracks whose hops are several rows of the fused kernel (TrackDesc::parts > 1; whole tracks only).
+__global__ void __launch_bounds__(256) k_hop_combine_rows(const TrackDesc *__restrict__ tracks,
+                                                          const RateDev *__restrict__ rates,
+                                                          const WorkItem *__restrict__ items,
+                                                          const HopRec *__restrict__ recs, double *__restrict__ hop_sums)
+{
+    const WorkItem it = items[blockIdx.x];
+    const TrackDesc &t = tracks[it.track];
+    if (t.parts <= 1) return;
+    const int C = t.ch;
+    const uint64_t pair = it.first + threadIdx.x;
+    if (pair >= t.n_hops * C) return;
+    const int64_t h = static_cast<int64_t>(pair / C);
+    const int c = static_cast<int>(pair % C);
+    const RateDev &r = rates[t.rate_idx];
+    const HopRec *base = recs + t.rec_base + kPreRec * C + c;  // row 0, channel c; stride C
+    // The hop is `parts` rows, each filtered from zero state (whole tracks only: nothing in front of row 0).  State at the
+    // first row's start: the end states of the sub_terms rows before it, by Horner; at the next rows' starts by the exact
+    // recurrence s' = Ms s + zend.  The hop's energy is the sum of its rows'.
+    const int P = static_cast<int>(t.parts), K = r.sub_terms;
+    const int64_t r0 = h * P;
+    double s[4] = {0, 0, 0, 0};
+    for (int k = K; k >= 1; k--) {
+        const int64_t rr = r0 - k;
+        if (rr < 0) continue;  // (s is still zero)
+        const double *z = base[rr * C].s;
+        double n[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double a = z[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
+            n[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[i] = n[i];
+    }
+    double H = 0;
+    for (int p = 0; p < P; p++) {
+        const HopRec &row = base[(r0 + p) * C];
+        double lin = 0, quad = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            lin = fma(s[i], row.q[i], lin);
+            double gs = 0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) gs = fma(r.Gs[i * 4 + j], s[j], gs);
+            quad = fma(s[i], gs, quad);
+        }
+        H += row.e0 + (2.0 * lin + quad);
+        double n[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            double a = row.s[i];
+#pragma unroll
+            for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
+            n[i] = a;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) s[i] = n[i];
+    }
+    if (H < 0) H = 0;
     hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;
 }
 
@@ -907,10 +926,12 @@ void launch_hop_zero_state(int fmt, const TrackDesc *tracks, const RateDev *rate
 }
 
 void launch_hop_combine(const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
-                        const HopRec *recs, double *hop_sums, hipStream_t st)
+                        const HopRec *recs, double *hop_sums, bool any_rows, hipStream_t st)
 {
     if (!n_items) return;
     hipLaunchKernelGGL(k_hop_combine, dim3(n_items), dim3(256), 0, st, tracks, rates, items, recs, hop_sums);
+    // (tracks whose hops are several rows: each kernel skips the other's tracks)
+    if (any_rows) hipLaunchKernelGGL(k_hop_combine_rows, dim3(n_items), dim3(256), 0, st, tracks, rates, items, recs, hop_sums);
 }
 
 // A track measured through stereo planes (TrackDesc::role 1): its hop sums are those of its planes' channels.
