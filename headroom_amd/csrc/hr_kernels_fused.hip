@@ -509,33 +509,16 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
             thr_l[ch][1] = 32 + (lane & 31) < n_rows ? thr : __builtin_inff();
         }
     };
-    // keep: frames of this piece (from its first) that count as samples of the output; the others (the final row's, in
-    // the positions libswresample never reaches) go into S_x instead of the lane's sample peak
-    auto make_frags = [&](auto slot_c, auto masked_c, int keep) {
+    auto make_frags = [&](auto slot_c) {
         constexpr int slot = decltype(slot_c)::value;
-        constexpr bool MASKED = decltype(masked_c)::value;
 #ifdef HR_EXP_NO_FRAGS
         if constexpr (DO_TP) { hist[slot][0][0][0] ^= __float_as_uint(v[0].x); return; }
 #endif
         if constexpr (DO_TP) {
-            if constexpr (MASKED) {
-                float ex[2] = {0.0f, 0.0f};
 #pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    const bool k0 = 2 * c < keep, k1 = 2 * c + 1 < keep;
-                    s_lane[0] = fmaxf(fmaxf(k0 ? fabsf(v[c].x) : 0.0f, k1 ? fabsf(v[c].z) : 0.0f), s_lane[0]);
-                    s_lane[1] = fmaxf(fmaxf(k0 ? fabsf(v[c].y) : 0.0f, k1 ? fabsf(v[c].w) : 0.0f), s_lane[1]);
-                    ex[0] = fmaxf(fmaxf(k0 ? 0.0f : fabsf(v[c].x), k1 ? 0.0f : fabsf(v[c].z)), ex[0]);
-                    ex[1] = fmaxf(fmaxf(k0 ? 0.0f : fabsf(v[c].y), k1 ? 0.0f : fabsf(v[c].w)), ex[1]);
-                }
-                S_x[0] = fmaxf(S_x[0], wave_max_f32(ex[0]));
-                S_x[1] = fmaxf(S_x[1], wave_max_f32(ex[1]));
-            } else {
-#pragma unroll
-                for (int c = 0; c < 8; c++) {
-                    s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
-                    s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
-                }
+            for (int c = 0; c < 8; c++) {
+                s_lane[0] = fmaxf(fmaxf(fabsf(v[c].x), fabsf(v[c].z)), s_lane[0]);
+                s_lane[1] = fmaxf(fmaxf(fabsf(v[c].y), fabsf(v[c].w)), s_lane[1]);
             }
             unsigned f[2][8];
 #pragma unroll
@@ -553,7 +536,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
                 }
         }
     };
-    make_frags(std::integral_constant<int, 2>{}, std::false_type{}, 16);  // the prologue piece is "piece -1"
+    make_frags(std::integral_constant<int, 2>{});  // the prologue piece is "piece -1"
 
     // tile bookkeeping (wave-uniform): the coefficient pattern of tile t is t mod NP
     const int NP = r.tp_np;
@@ -705,12 +688,29 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
                 pat = pat + 1 == NP ? 0 : pat + 1;
             }
         }
-        // fragments of piece k go into slot k mod 3
-        if (DO_TP && k >= k_fin) {  // (wave-uniform: the last steps of the wave that holds the track's last fused row)
-            make_frags(slot_c, std::true_type{}, lane >= last_row ? fin_keep_now() - 16 * k : 16);
-            refresh_bounds();                     // (the thresholds must see S_x before this step's tile is screened)
-        } else {
-            make_frags(slot_c, std::false_type{}, 16);
+        // fragments of piece k go into slot k mod 3.  In the last steps of the wave that holds the track's last fused row
+        // (wave-uniform, rare) the frames at or beyond fin_keep are no samples of the output: the lane's sample peak is put
+        // back to what it was plus the frames that count, the others go into S_x, and the bounds are refreshed below so
+        // that the thresholds see S_x before this step's tile is screened.
+        float force_refresh = 0.0f;
+        const float keep0 = s_lane[0], keep1 = s_lane[1];
+        make_frags(slot_c);
+        if (DO_TP && k >= k_fin) {
+            const int keep = lane >= last_row ? fin_keep_now() - 16 * k : 16;
+            float in0 = keep0, in1 = keep1, ex0 = 0.0f, ex1 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const bool k0 = 2 * c < keep, k1 = 2 * c + 1 < keep;
+                in0 = fmaxf(fmaxf(k0 ? fabsf(v[c].x) : 0.0f, k1 ? fabsf(v[c].z) : 0.0f), in0);
+                in1 = fmaxf(fmaxf(k0 ? fabsf(v[c].y) : 0.0f, k1 ? fabsf(v[c].w) : 0.0f), in1);
+                ex0 = fmaxf(fmaxf(k0 ? 0.0f : fabsf(v[c].x), k1 ? 0.0f : fabsf(v[c].z)), ex0);
+                ex1 = fmaxf(fmaxf(k0 ? 0.0f : fabsf(v[c].y), k1 ? 0.0f : fabsf(v[c].w)), ex1);
+            }
+            s_lane[0] = in0;
+            s_lane[1] = in1;
+            S_x[0] = fmaxf(S_x[0], wave_max_f32(ex0));
+            S_x[1] = fmaxf(S_x[1], wave_max_f32(ex1));
+            force_refresh = 1.0f;
         }
         if constexpr (!DO_TP) {
             if (dbg & 64) {
@@ -728,7 +728,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
             // (S itself is one: phase 0 of the bank passes the samples through), so an output below lb - err
             // cannot be the maximum.  The wave-wide values are recomputed only when some lane has outgrown them.
             // (one compare: a VALU compare that feeds a scalar branch costs as much as half a dozen f32 operations)
-            const float over = fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1]));
+            const float over = fmaxf(fmaxf(fmaxf(s_lane[0] - S_u[0], s_lane[1] - S_u[1]), fmaxf(alb[0] - A_u[0], alb[1] - A_u[1])), force_refresh);
             const bool stale = over > 0.0f;
 #ifdef HR_EXP_NO_BOUNDS
             asm volatile("" :: "v"(over));
