@@ -267,6 +267,7 @@ void add_desc(Group &g, const hr_track &t, const void *dev_pcm, int rate_idx, bo
     d.row_len = d.hop;
     d.parts = 1;
     d.n_hops = t.frames / d.hop;
+    d.sub_from = d.n_hops;
     d.ch = t.channels;
     d.fmt = t.fmt;
     d.rate_idx = rate_idx;
@@ -339,72 +340,102 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     // times the rows, a third of the steps, at a few steps of fixed cost per row (the start of a row accumulates all
     // four carry products; its last piece is partial).  Whole tracks whose last hop is a fused row only; never time shards.
     const bool sub_ok = !ctx->split && !ctx->no_alloc && ctx->shard_group != &g && ctx->cfg.engine != 2;
+    // per track: hops [0, sub_from) are one row each, hops [sub_from, n_hops) are sub_p rows each (sub_from == n_hops: none)
     std::vector<uint32_t> sub_p(nt, 1);
+    std::vector<uint64_t> sub_from(nt, 0);
+    for (size_t i = 0; i < nt; i++) sub_from[i] = g.descs[i].n_hops;
     {
-        auto final_row_ok = [&](const TrackDesc &d, uint64_t rows, uint64_t len) {  // (see ffin below)
+        auto final_row_ok = [&](const TrackDesc &d, uint64_t len) {  // (see ffin below)
             const uint32_t fb = fmt_bytes(d.fmt) * 2;
             const uint64_t align = fb == 8 ? 2 : fb == 4 ? 4 : 8, T = (len + 15) / 16;
-            return d.stream_end && !d.right_head && (d.frames - (rows - 1) * len >= 16 * (T + 1) || d.frames % align == 0);
+            return d.stream_end && !d.right_head && (d.frames - (d.n_hops * d.hop - len) >= 16 * (T + 1) || d.frames % align == 0);
         };
-        std::vector<uint64_t> w1(nt, 0), wP(nt, 0), t1(nt, 0), tP(nt, 0);  // waves of the track, steps of one of its waves
+        // waves and wave-steps of a track as whole hops (0), as shorter rows throughout (1), and with only the hops that
+        // do not fill a wave of whole-hop rows as shorter rows (2: those waves run a third of the steps)
+        struct Cost { uint64_t waves[3] = {0, 0, 0}, steps[3] = {0, 0, 0}; bool can = false; };
+        std::vector<Cost> cost(nt);
         for (size_t i = 0; i < nt && sub_ok; i++) {
             const TrackDesc &d = g.descs[i];
             if (!fkw[i]) continue;
             const RateDev &rd = ctx->rates_h[d.rate_idx];
-            t1[i] = (d.hop + 15) / 16 + 1;
-            w1[i] = (d.n_hops + 63) / 64;
+            Cost &c = cost[i];
+            const uint64_t t1 = (d.hop + 15) / 16 + 1;
+            c.waves[0] = (d.n_hops + 63) / 64;
+            c.steps[0] = c.waves[0] * t1;
             const uint64_t P = static_cast<uint64_t>(rd.sub_parts);
             const uint64_t len = P > 1 ? d.hop / P : d.hop;
-            const bool can = P > 1 && !d.left_tail && !d.right_head && d.blk_first == 0 && d.stream_start &&
-                             (len * fmt_bytes(d.fmt) * 2) % 16 == 0 && final_row_ok(d, d.n_hops * P, len);
-            tP[i] = can ? (len + 15) / 16 + 1 : t1[i];
-            wP[i] = can ? (d.n_hops * P + 63) / 64 : w1[i];
+            c.can = P > 1 && !d.left_tail && !d.right_head && d.blk_first == 0 && d.stream_start &&
+                    (len * fmt_bytes(d.fmt) * 2) % 16 == 0 && final_row_ok(d, len);
+            for (int k = 1; k < 3; k++) { c.waves[k] = c.waves[0]; c.steps[k] = c.steps[0]; }
+            if (!c.can) continue;
+            const uint64_t tP = (len + 15) / 16 + 1;
+            c.waves[1] = (d.n_hops * P + 63) / 64;
+            c.steps[1] = c.waves[1] * tP;
+            const uint64_t left = d.n_hops % 64, full = d.n_hops / 64;
+            if (left && full) {
+                const uint64_t wl = (left * P + 63) / 64;
+                c.waves[2] = full + wl;
+                c.steps[2] = full * t1 + wl * tP;
+            }
         }
+        // the track's own best: fuller waves must pay for the fixed cost of more rows (3 %); shorter LAST waves cost nothing
+        auto own_choice = [&](size_t i) {
+            const Cost &c = cost[i];
+            if (!c.can) return 0;
+            int best = 0;
+            if (c.steps[2] * 1000 < c.steps[0] * 995) best = 2;
+            if (c.steps[1] * 100 < c.steps[best] * 97) best = 1;
+            return best;
+        };
         // What a launch costs, in steps: its waves run in rounds of the GPU's wave slots, a last partial round costs half
         // a round plus its share (measured: profiles/README.md, round 2), one round or less costs one wave's steps.
-        auto estimate = [&](auto uses_sub) {
+        auto estimate = [&](auto choice) {
             double waves = 0, steps = 0;
             for (size_t i = 0; i < nt; i++) {
-                if (!w1[i]) continue;
-                const bool sub = uses_sub(i);
-                waves += static_cast<double>(sub ? wP[i] : w1[i]);
-                steps += static_cast<double>(sub ? wP[i] * tP[i] : w1[i] * t1[i]);
+                if (!cost[i].waves[0]) continue;
+                const int k = choice(i);
+                waves += static_cast<double>(cost[i].waves[k]);
+                steps += static_cast<double>(cost[i].steps[k]);
             }
             if (waves == 0) return 0.0;
             const double rounds = waves / 2048.0, whole = std::floor(rounds), frac = rounds - whole;
             const double eff = rounds <= 1.0 ? 1.0 : whole + (frac > 0 ? 0.5 + 0.5 * frac : 0.0);
             return eff * steps / waves;
         };
-        auto per_track = [&](size_t i) { return wP[i] * tP[i] * 100 < w1[i] * t1[i] * 97; };  // the track's own waves get fuller
-        auto all_sub = [&](size_t i) { return wP[i] != w1[i]; };
-        const double est_a = estimate([](size_t) { return false; }), est_b = estimate(per_track), est_c = estimate(all_sub);
-        int plan = 0;  // 0: whole hops; 1: shorter rows where a track's waves get fuller; 2: wherever a track allows them
-        // (measured: over several rounds shorter rows everywhere gain nothing -- 1000 three-minute tracks 19.8 against
-        // 19.65 ms, and their combine kernel costs 0.4 ms more -- so plan 2 is for launches of at most one round)
+        auto all_sub = [&](size_t i) { return cost[i].can ? 1 : 0; };
+        const double est_b = estimate(own_choice), est_c = estimate(all_sub);
         double waves_a = 0;
-        for (size_t i = 0; i < nt; i++) waves_a += static_cast<double>(w1[i]);
-        if (ctx->cfg.engine == 3) plan = 2;
-        else if (waves_a <= 2048.0 && est_c < 0.985 * est_a && est_c <= est_b) plan = 2;
-        else if (est_b < 0.985 * est_a) plan = 1;
-        for (size_t i = 0; i < nt && sub_ok; i++)
-            if (w1[i] && wP[i] != w1[i] && (plan == 2 || (plan == 1 && per_track(i)))) sub_p[i] = static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].sub_parts);
+        for (size_t i = 0; i < nt; i++) waves_a += static_cast<double>(cost[i].waves[0]);
+        // (measured: over several rounds shorter rows everywhere gain nothing -- 1000 three-minute tracks 19.8 against
+        // 19.65 ms, and their combine kernel costs 0.4 ms more -- so that is for launches of at most one round)
+        const bool everywhere = ctx->cfg.engine == 3 || (waves_a <= 2048.0 && est_c < 0.985 * est_b);
+        for (size_t i = 0; i < nt && sub_ok; i++) {
+            if (!cost[i].can) continue;
+            int k = everywhere ? 1 : own_choice(i);
+            if (ctx->cfg.engine == 4) k = cost[i].steps[2] != cost[i].steps[0] ? 2 : 0;
+            if (k == 0) continue;
+            sub_p[i] = static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].sub_parts);
+            sub_from[i] = k == 1 ? 0 : g.descs[i].n_hops / 64 * 64;
+        }
     }
     g.rec_slots = 0;
     for (size_t i = 0; i < nt; i++) {
         TrackDesc &d = g.descs[i];
         d.parts = sub_p[i];
+        d.sub_from = sub_from[i];
         d.row_len = d.hop / d.parts;
         d.rec_base = g.rec_slots;
-        g.rec_slots += (d.n_hops * d.parts + kPreRec) * d.ch;
+        g.rec_slots += (sub_from[i] + (d.n_hops - sub_from[i]) * d.parts + kPreRec) * d.ch;
     }
     if (!ctx->recs.ensure((g.rec_slots + 8) * sizeof(HopRec))) return HR_ERR_OOM;
+    std::vector<uint64_t> tail_rows_of(nt, 0);
     for (size_t i = 0; i < nt; i++) {
         TrackDesc &d = g.descs[i];
         d.fin_tail = 0;
         d.fin_valid = 0;
         if (!fkw[i]) continue;
-        const uint64_t len = d.row_len, rows = d.n_hops * d.parts;
-        const uint64_t last_hop0 = (rows - 1) * len;  // (start of the last row that holds a whole hop's frames)
+        const uint64_t len = sub_from[i] < d.n_hops ? d.row_len : d.hop;  // rows of the track's last section
+        const uint64_t last_hop0 = d.n_hops * d.hop - len;  // (start of the last row that belongs to a hop)
         fend[i] = last_hop0;
         if (!d.stream_end || d.right_head || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
         const uint64_t ragged = d.frames - d.n_hops * d.hop;
@@ -422,9 +453,10 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             tail_rows = usable / len;
             if (usable - tail_rows * len >= 48) tail_rows++;
         }
+        tail_rows_of[i] = tail_rows;
         if (tail_rows) {
             d.fin_tail = static_cast<uint8_t>(tail_rows);
-            const uint64_t l0 = (rows + tail_rows - 1) * len;
+            const uint64_t l0 = d.n_hops * d.hop + (tail_rows - 1) * len;
             d.fin_valid = static_cast<uint32_t>(d.n_hops * d.hop + usable - l0);
             const uint64_t keep = d.fin_valid > d.tp_drop ? d.fin_valid - d.tp_drop : 0;
             fend[i] = l0 + 16 * std::min<uint64_t>(keep / 16, T);
@@ -452,22 +484,44 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         class_off[cls] = fitems.size();
         for (size_t rp = 0; rp < 2 * ctx->rates_h.size(); rp++) {  // (rate, whole-hop rows) then (rate, shorter rows)
             const size_t ri = rp / 2;
+            const bool shorter = rp % 2 == 1;
             const size_t run_begin = fitems.size();
             for (size_t i = 0; i < nt; i++) {
-                if (!fkw[i] || g.descs[i].rate_idx != static_cast<int32_t>(ri) || (g.descs[i].parts > 1) != (rp % 2 == 1)) continue;
+                const TrackDesc &d = g.descs[i];
+                if (!fkw[i] || d.rate_idx != static_cast<int32_t>(ri)) continue;
                 const RateDev &rd = ctx->rates_h[ri];
                 const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
                 if (mine != cls) continue;
-                const uint64_t interior = g.descs[i].n_hops * g.descs[i].parts - (ffin[i] ? 0 : 1) + g.descs[i].fin_tail;
-                for (uint64_t h = 0; h < interior; h += 64)
-                    fitems.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min<uint64_t>(64, interior - h)), h});
-            }
-            if (fitems.size() > run_begin)
-                while ((fitems.size() - run_begin) % kFusedWaves) {
-                    FusedItem pad = fitems.back();
-                    pad.n_rows = 0;
-                    fitems.push_back(pad);
+                // this section's rows: record rows [r0, r1) from frame f0 on, `len` frames each; the track's last section
+                // also holds the rows behind the last hop, and loses the final hop's row when that one stays generic
+                const bool has_sub = sub_from[i] < d.n_hops;
+                uint64_t r0, r1, f0, len;
+                if (!shorter) {
+                    r0 = 0; r1 = sub_from[i]; f0 = 0; len = d.hop;
+                    if (!has_sub) r1 = r1 - (ffin[i] ? 0 : 1) + tail_rows_of[i];
+                } else {
+                    if (!has_sub) continue;
+                    r0 = sub_from[i]; r1 = sub_from[i] + (d.n_hops - sub_from[i]) * d.parts + tail_rows_of[i];
+                    f0 = sub_from[i] * d.hop; len = d.row_len;
                 }
+                const bool last_section = shorter == has_sub;
+                for (uint64_t r = r0; r < r1; r += 64) {
+                    FusedItem it{};
+                    it.track = static_cast<uint32_t>(i);
+                    it.n_rows = static_cast<uint32_t>(std::min<uint64_t>(64, r1 - r));
+                    it.first_hop = r;
+                    it.frame0 = f0 + (r - r0) * len;
+                    it.row_len = static_cast<uint32_t>(len);
+                    it.last = last_section && ffin[i] && r + 64 >= r1;
+                    fitems.push_back(it);
+                }
+            }
+            if (fitems.size() > run_begin) {
+                FusedItem pad = fitems.back();
+                pad.last = pad.last && pad.n_rows == 1;  // (a padding wave works on row 0 of the wave it copies)
+                pad.n_rows = 0;
+                while ((fitems.size() - run_begin) % kFusedWaves) fitems.push_back(pad);
+            }
         }
     }
     class_off[kFusedClasses] = fitems.size();
@@ -907,7 +961,7 @@ try {
     *out = nullptr;
     hr_config c{};
     if (cfg) c = *cfg;
-    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 3) return HR_ERR_INVALID;
+    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 4) return HR_ERR_INVALID;
     const int n = hr_device_count();
     if (n <= 0) return HR_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;

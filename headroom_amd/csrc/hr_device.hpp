@@ -95,9 +95,11 @@ struct TrackDesc {
                            // be fetched (16-byte chunks that start inside them end inside the track)
     uint64_t first_hop;    // index of hop 0 in the whole stream (libebur128 takes its range blocks on a 1 s grid)
     uint32_t part_base, n_parts;  // gating chunks of kGateChunk blocks (one workgroup each): slots of their partial sums
-    // rows of the fused kernel: a hop is `parts` rows of row_len = hop / parts frames (1 and hop unless run_measure
-    // decides otherwise); zero-state records are per row: (row r, ch c) is rec_base + (kPreRec + r)*ch + c
+    // rows of the fused kernel (run_measure): hops [0, sub_from) are one row each, hops [sub_from, n_hops) are `parts` rows
+    // of row_len = hop / parts frames each (sub_from == n_hops, parts == 1: whole hops throughout).  Zero-state records
+    // are per row, numbered in that order: (row r, ch c) is rec_base + (kPreRec + r)*ch + c
     uint32_t row_len, parts;
+    uint64_t sub_from;
     float w[kMaxCh];
 };
 
@@ -111,8 +113,11 @@ struct WorkItem {
 // one wave's share of the fused kernel: up to 64 consecutive interior hops of one track
 struct FusedItem {
     uint32_t track;
-    uint32_t n_rows;
-    uint64_t first_hop;
+    uint32_t n_rows;     // 0: a padding wave (works on row 0 of the item it copies, reports nothing)
+    uint64_t first_hop;  // record row of the wave's first row: (row r, ch c) is rec_base + (kPreRec + r)*ch + c
+    uint64_t frame0;     // frame at which that row starts
+    uint32_t row_len;    // frames per row: a hop, or a whole fraction of one
+    uint32_t last;       // the wave's last row is the track's last fused row (TrackDesc::fin_valid)
 };
 
 struct TrackOut {  // what the finalize kernel hands to the host

@@ -344,7 +344,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     const RateDev &r = rates[t.rate_idx];
     const bool passthru0 = r.tp_passthru0 != 0;  // else (BS.1770 bank) the sample peak bounds nothing and phase 0 is screened
     const KCoef kc = r.k;
-    const uint32_t hop = t.row_len;  // frames per row: a hop, or (TrackDesc::parts > 1) a whole fraction of one
+    const uint32_t hop = it.row_len;  // frames per row: a hop, or a whole fraction of one
     const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
     const int n_rows = static_cast<int>(it.n_rows);  // 0: a padding item (computes on row 0, reports nothing)
     const int last_row = n_rows > 0 ? n_rows - 1 : 0;
@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     constexpr unsigned PB = 16 * FB;            // piece bytes
     constexpr int NDMA = PB / 16;               // DMA instructions per piece set (64 rows): 8, 4 or 6
     constexpr int LPP = PB / 16;                // lanes per piece
-    const char *wave_base = static_cast<const char *>(t.pcm) + it.first_hop * hop * static_cast<unsigned long long>(FB);
+    const char *wave_base = static_cast<const char *>(t.pcm) + it.frame0 * static_cast<unsigned long long>(FB);
     char *lbuf = smem + wave * kPieceLds;
     char *abuf = smem + kFusedWaves * kPieceLds;    // [2][9 KiB]: step k reads half k&1
     char *gbuf = abuf + 2 * kCoefLds;     // [2][1 KiB]: step k reads half k&1
@@ -398,7 +398,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     // row, the padding wave needs the same care -- it reads the same bytes)
     // One number stays live for all of this: k_fin, the first step that needs any care (the piece that holds frame
     // fin_keep; never, in every other wave).  The rare steps fetch the rest from the descriptor again.
-    const bool fin_wave = it.first_hop + static_cast<uint64_t>(last_row + 1) == t.n_hops * t.parts + t.fin_tail;
+    const bool fin_wave = it.last != 0;
     const int k_fin = fin_wave ? (static_cast<int>(t.fin_valid) > t.tp_drop ? (static_cast<int>(t.fin_valid) - t.tp_drop) / 16 : 0) : (1 << 30);
     auto fin_valid_now = [&]() {
         const TrackDesc *tp = &t;
@@ -428,7 +428,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
         const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * FB);
         const unsigned *rowq = reinterpret_cast<const unsigned *>(rowp);  // s16: one dword per frame
         const uint8_t *rowb = reinterpret_cast<const uint8_t *>(rowp);    // s24: six bytes per frame
-        if (h > 0) {
+        if (it.frame0 > 0 || row > 0) {  // (not the track's first row)
 #pragma unroll
             for (int c = 0; c < 8; c++) {
                 if constexpr (INF == 2) {
@@ -987,7 +987,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
         run(k_split, T + 1, std::true_type{});
     }
 
-    if (DO_KW && lane < n_rows && h < t.n_hops * t.parts) {  // (the ragged tail as a row, behind the last hop, is there for its peak only)
+    if (DO_KW && lane < n_rows && h < t.sub_from + (t.n_hops - t.sub_from) * t.parts) {  // (rows behind the last hop are there for their peak only)
 #pragma unroll
         for (int c = 0; c < 2; c++) {
             if (k_short <= T) {
@@ -1484,7 +1484,7 @@ __global__ void __launch_bounds__(256) k_refine_cands(const TrackDesc *__restric
         const long num0 = 16L * tile * P, num1 = 16L * (tile + 1) * P;
         const int m_lo = static_cast<int>((num0 + step - 1) / step);
         const int count = static_cast<int>((num1 + step - 1) / step) - m_lo;
-        const int64_t row_frame0 = static_cast<int64_t>(it.first_hop + crow) * t.row_len;
+        const int64_t row_frame0 = static_cast<int64_t>(it.frame0) + static_cast<int64_t>(crow) * it.row_len;
         for (int i = 0; i < 16; i++) {
             const int rowidx = 32 * mt + 4 * half + (i & 3) + 8 * (i >> 2);
             if (rowidx >= count) continue;

@@ -180,7 +180,7 @@ __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict
     const RateDev &r = rates[t.rate_idx];
 
     const HopRec *base = recs + t.rec_base + kPreRec * C + c;  // hop 0, channel c; stride C
-    if (t.parts > 1) return;  // (k_hop_combine_rows)
+    if (h >= static_cast<int64_t>(t.sub_from)) return;  // (a hop of several rows: k_hop_combine_rows)
     const HopRec &me = base[h * C];
     // records in front of hop 0 exist only for a shard with a left neighbour (blk_first < 0)
     const bool edge = t.blk_first < 0;
@@ -215,7 +215,12 @@ __global__ void __launch_bounds__(256) k_hop_combine(const TrackDesc *__restrict
     hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;
 }
 
-// The same for tracks whose hops are several rows of the fused kernel (TrackDesc::parts > 1; whole tracks only).
+// The hops that are several rows of the fused kernel (TrackDesc::sub_from .. n_hops - 1, `parts` rows each; whole tracks
+// only: nothing in front of row 0).  Every row was filtered from zero state.  State at the hop's first row: when the
+// sub_terms rows behind it are all short rows, their end states by Horner (the truncation is negligible: RateTables::
+// sub_residual); otherwise the state at hop sub_from -- from the whole-hop records in front of it, as k_hop_combine
+// forms it -- carried through the short rows in between by the exact recurrence s' = Ms s + zend.  The same
+// recurrence steps through the hop's own rows; the hop's energy is the sum of theirs.
 __global__ void __launch_bounds__(256) k_hop_combine_rows(const TrackDesc *__restrict__ tracks,
                                                           const RateDev *__restrict__ rates,
                                                           const WorkItem *__restrict__ items,
@@ -228,19 +233,14 @@ __global__ void __launch_bounds__(256) k_hop_combine_rows(const TrackDesc *__res
     const uint64_t pair = it.first + threadIdx.x;
     if (pair >= t.n_hops * C) return;
     const int64_t h = static_cast<int64_t>(pair / C);
+    if (h < static_cast<int64_t>(t.sub_from)) return;
     const int c = static_cast<int>(pair % C);
     const RateDev &r = rates[t.rate_idx];
     const HopRec *base = recs + t.rec_base + kPreRec * C + c;  // row 0, channel c; stride C
-    // The hop is `parts` rows, each filtered from zero state (whole tracks only: nothing in front of row 0).  State at the
-    // first row's start: the end states of the sub_terms rows before it, by Horner; at the next rows' starts by the exact
-    // recurrence s' = Ms s + zend.  The hop's energy is the sum of its rows'.
     const int P = static_cast<int>(t.parts), K = r.sub_terms;
-    const int64_t r0 = h * P;
-    double s[4] = {0, 0, 0, 0};
-    for (int k = K; k >= 1; k--) {
-        const int64_t rr = r0 - k;
-        if (rr < 0) continue;  // (s is still zero)
-        const double *z = base[rr * C].s;
+    const int64_t H1 = static_cast<int64_t>(t.sub_from);
+    const int64_t r0 = H1 + (h - H1) * P;  // the hop's first row
+    auto step = [&](double (&s)[4], const double *z) {  // s = Ms s + z
         double n[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -251,7 +251,31 @@ __global__ void __launch_bounds__(256) k_hop_combine_rows(const TrackDesc *__res
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) s[i] = n[i];
+    };
+    double s[4] = {0, 0, 0, 0};
+    int64_t from = r0 - K;  // first row whose end state enters
+    if (from < H1) {
+        from = H1;
+        if (H1 > 0) {  // the state at hop H1 from the whole-hop records H1-1, H1-2, H1-3 (k_hop_combine's series)
+            double p1[4], p2[4], p3[4];
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                p1[i] = base[(H1 - 1) * C].s[i];
+                p2[i] = H1 - 2 >= 0 ? base[(H1 - 2) * C].s[i] : 0.0;
+                p3[i] = H1 - 3 >= 0 ? base[(H1 - 3) * C].s[i] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                double a = p1[i];
+#pragma unroll
+                for (int j = 0; j < 4; j++) a = fma(r.M1[i * 4 + j], p2[j], a);
+#pragma unroll
+                for (int j = 0; j < 4; j++) a = fma(r.M2[i * 4 + j], p3[j], a);
+                s[i] = a;
+            }
+        }
     }
+    for (int64_t rr = from; rr < r0; rr++) step(s, base[rr * C].s);
     double H = 0;
     for (int p = 0; p < P; p++) {
         const HopRec &row = base[(r0 + p) * C];
@@ -265,16 +289,7 @@ __global__ void __launch_bounds__(256) k_hop_combine_rows(const TrackDesc *__res
             quad = fma(s[i], gs, quad);
         }
         H += row.e0 + (2.0 * lin + quad);
-        double n[4];
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            double a = row.s[i];
-#pragma unroll
-            for (int j = 0; j < 4; j++) a = fma(r.Ms[i * 4 + j], s[j], a);
-            n[i] = a;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) s[i] = n[i];
+        step(s, row.s);
     }
     if (H < 0) H = 0;
     hop_sums[t.hop_base + (kPreHop + h) * C + c] = H;

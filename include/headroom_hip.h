@@ -70,8 +70,9 @@ typedef struct hr_config {
     int32_t gate_mode;  /* HR_GATE_*                                                        */
     int32_t tp_mode;    /* HR_TP_*                                                          */
     int32_t engine;     /* 0 = default (fastest available), 1 = force the generic kernels;
-                           2 / 3 = the fast kernels with rows of a whole hop only / of a fraction of a hop wherever a
-                           track allows it (0 chooses per track and launch; same results, for tests and timing) */
+                           2 / 3 / 4 = the fast kernels with rows of a whole hop only / of a fraction of a hop wherever
+                           a track allows it / of a fraction of a hop for the hops that do not fill a wave (0 chooses
+                           per track and launch; same results, for tests and timing) */
     void *stream;       /* hipStream_t to run on, or NULL for a stream owned by the context */
     uint64_t stage_bytes; /* device staging for host-resident PCM; 0 = default (1 GiB)      */
 } hr_config;

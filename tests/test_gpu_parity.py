@@ -790,3 +790,22 @@ def test_largest_sample_near_the_end_of_a_sharded_stream(oracle, meters, ragged)
     finally:
         for mm in ms:
             mm.close()
+
+
+@pytest.mark.parametrize("engine", [2, 3, 4])
+@pytest.mark.parametrize("fs", [44100, 48000, 96000])
+def test_row_lengths_of_the_fused_kernel(oracle, meters, fs, engine):
+    """hr_config.engine 2 / 3 / 4: rows of a whole hop, of a fraction of a hop, and both in one track (whole-hop rows for
+    the hops that fill waves, shorter ones behind them): the carry crosses the sections' boundary.  Low-frequency content on
+    a DC offset makes the carry terms as large as the zero-state energies; tracks of 70 and 133 hops and a bit."""
+    for seconds, ragged in ((7.0, 1234), (13.3, 0), (13.3, 4000)):
+        n = int(fs * seconds) + ragged
+        t = np.arange(n) / fs
+        pcm = np.stack([0.4 * np.sin(2 * np.pi * 25.0 * t) + 0.3, 0.2 * np.cos(2 * np.pi * 31.0 * t) - 0.25], axis=1).astype(np.float32)
+        pcm += signals.seeded_noise(int(seconds) + ragged, n, 2, -30.0)
+        pcm[n - 40, 0] = 0.97          # a peak near the end, in front of the positions without output
+        m = meters(engine=engine)
+        H, P = m.block_energies(hr.TrackSpec(pcm, fs))
+        Href = oracle.hop_sums(pcm, fs)
+        assert H.shape == Href.shape and np.max(np.abs(H / Href - 1)) < 1e-9
+        check_against_oracle(oracle, m, pcm, fs)
