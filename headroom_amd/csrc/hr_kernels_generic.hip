@@ -622,7 +622,12 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
     TrackOut &o = outs[blockIdx.x];
     const bool ln = gate_mode == 2;
     const int nbins = ln ? kLnBins : kEbuBins;
-    const uint32_t *hh = st_hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
+    // the track's histogram, read once, coalesced, into LDS; every thread then walks its own 32 consecutive bins there
+    // (one padding slot per 32 bins: the threads' walks start in different banks)
+    __shared__ uint32_t lh[kEbuBins + kEbuBins / 32 + 1];
+    const uint32_t *hg = st_hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i + (i >> 5)] = hg[i];
+    auto hh = [&](int i) { return lh[i + (i >> 5)]; };
     if (threadIdx.x == 0) { lo_bin = nbins; hi_bin = ln ? nbins : -1; }
     __syncthreads();
     double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
@@ -651,7 +656,7 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
     } else {
         double gs = 0;
         unsigned long long cnt = 0;
-        for (int i = c0; i < c1; i++) { cnt += hh[i]; gs += static_cast<double>(hh[i]) * ln_energy[i]; }
+        for (int i = c0; i < c1; i++) { cnt += hh(i); gs += static_cast<double>(hh(i)) * ln_energy[i]; }
         const double g1 = block_reduce_sum(gs, shd);
         const unsigned long long a1 = block_reduce_sum_u64(cnt, shu);
         any = a1 != 0;
@@ -671,7 +676,7 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
     }
     if (any) {  // uniform across the workgroup
         unsigned long long mine = 0;
-        for (int i = c0 > first ? c0 : first; i < c1; i++) mine += hh[i];
+        for (int i = c0 > first ? c0 : first; i < c1; i++) mine += hh(i);
         shu[threadIdx.x] = mine;
         __syncthreads();
         unsigned long long E = 0, total = 0;
@@ -688,17 +693,22 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
                 need_lo = static_cast<unsigned long long>(static_cast<double>(total - 1) * 0.1 + 0.5);
                 need_hi = static_cast<unsigned long long>(static_cast<double>(total - 1) * 0.95 + 0.5);
             }
+            // (this thread's bins first, then one atomic per thread and bound)
+            int my_lo = nbins, my_hi = ln ? nbins : -1;
             for (int i = c0 > first ? c0 : first; i < c1; i++) {
-                const unsigned long long incl = E + hh[i];
+                const unsigned long long incl = E + hh(i);
                 if (!ln) {
-                    if (incl >= need_lo) atomicMin(&lo_bin, i);  // first bin whose running count reaches the 10 % count
-                    if (E < need_hi) atomicMax(&hi_bin, i);      // last bin with fewer than the 95 % count below it
+                    if (incl >= need_lo && i < my_lo) my_lo = i;  // first bin whose running count reaches the 10 % count
+                    if (E < need_hi && i > my_hi) my_hi = i;      // last bin with fewer than the 95 % count below it
                 } else {
-                    if (incl > need_lo) atomicMin(&lo_bin, i);
-                    if (incl > need_hi) atomicMin(&hi_bin, i);
+                    if (incl > need_lo && i < my_lo) my_lo = i;
+                    if (incl > need_hi && i < my_hi) my_hi = i;
                 }
                 E = incl;
             }
+            if (my_lo < nbins) atomicMin(&lo_bin, my_lo);
+            if (!ln) { if (my_hi >= 0) atomicMax(&hi_bin, my_hi); }
+            else if (my_hi < nbins) atomicMin(&hi_bin, my_hi);
         }
         __syncthreads();
         any = total != 0;
