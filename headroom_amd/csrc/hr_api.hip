@@ -530,7 +530,49 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         if (rc) return rc;
     }
 
-    // work items of the generic kernels: [fmt] hop items, combine items, [fmt][kind] peak items -- one upload
+    FusedScratch fs{};
+    if (!fitems.empty()) {
+        if (!ctx->cands.ensure(fused_cand_bytes(static_cast<uint32_t>(fitems.size()))) ||
+            !ctx->cand_cnt.ensure(fitems.size() * sizeof(unsigned)) || !ctx->tpb.ensure(nt * kMaxCh * 2 * sizeof(unsigned)) ||
+            !ctx->overflow.ensure(nt * sizeof(unsigned)))
+            return HR_ERR_OOM;
+        fs.cands = ctx->cands.p;
+        fs.cand_cnt = ctx->cand_cnt.as<unsigned>();
+        fs.tpb = ctx->tpb.as<unsigned>();
+        fs.overflow = ctx->overflow.as<unsigned>();
+        HIPCHK(hipMemsetAsync(ctx->tpb.p, 0, nt * kMaxCh * 2 * sizeof(unsigned), st));
+        HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
+    }
+    ctx->h_ftp.assign(ftp.begin(), ftp.end());
+
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
+    // fork point for the generic kernels on the side stream: everything they and the fused kernel share (descriptors,
+    // rate tables, the zeroed peak slots) has been issued on st before it
+    hipStream_t tail_st = ctx->serial_tail ? st : ctx->side;
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    {
+        const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
+        // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
+        const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
+        for (int cls = 0; cls < kFusedClasses; cls++) {
+            const size_t off = class_off[cls], n = class_off[cls + 1] - off;
+            if (!n) continue;
+            FusedScratch fsc = fs;
+            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
+            fsc.cand_cnt = fs.cand_cnt + off;
+            const bool tp = cls < 6;
+            launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
+                              ctx->peaks.as<unsigned long long>(),
+                              cls >= 14 ? 6 : cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
+                              cls >= 14 ? cls - 14 : cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
+    // The fused kernel is on its way: the host builds the work items of the generic kernels beside it ([fmt] hop items,
+    // combine items, [fmt][kind] peak items -- one upload, on the side stream, where their kernels follow it)
     std::vector<WorkItem> &items = ctx->h_items;
     items.clear();
     struct Span { size_t off, n; };
@@ -584,32 +626,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             pk_span[f][kind].n = items.size() - pk_span[f][kind].off;
         }
     if (!items.empty()) {
-        rc = upload(ctx->items_d, items.data(), items.size() * sizeof(WorkItem), st);
+        rc = upload(ctx->items_d, items.data(), items.size() * sizeof(WorkItem), tail_st);
         if (rc) return rc;
     }
     const WorkItem *di = ctx->items_d.as<WorkItem>();
 
-    FusedScratch fs{};
-    if (!fitems.empty()) {
-        if (!ctx->cands.ensure(fused_cand_bytes(static_cast<uint32_t>(fitems.size()))) ||
-            !ctx->cand_cnt.ensure(fitems.size() * sizeof(unsigned)) || !ctx->tpb.ensure(nt * kMaxCh * 2 * sizeof(unsigned)) ||
-            !ctx->overflow.ensure(nt * sizeof(unsigned)))
-            return HR_ERR_OOM;
-        fs.cands = ctx->cands.p;
-        fs.cand_cnt = ctx->cand_cnt.as<unsigned>();
-        fs.tpb = ctx->tpb.as<unsigned>();
-        fs.overflow = ctx->overflow.as<unsigned>();
-        HIPCHK(hipMemsetAsync(ctx->tpb.p, 0, nt * kMaxCh * 2 * sizeof(unsigned), st));
-        HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
-    }
-    ctx->h_ftp.assign(ftp.begin(), ftp.end());
-
-    HIPCHK(hipEventRecord(ctx->ev[0], st));
-    if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
-    // fork: generic kernels on the side stream (everything they read has been issued on st before this point)
-    hipStream_t tail_st = ctx->serial_tail ? st : ctx->side;
-    HIPCHK(hipEventRecord(ctx->ev_fork, st));
-    if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
     for (int f = 0; f < 5; f++)
         launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), tail_st);
     for (int f = 0; f < 3; f++)
@@ -625,25 +646,6 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             }
     }
     HIPCHK(hipEventRecord(ctx->ev_join, tail_st));
-    HIPCHK(hipEventRecord(ctx->ev[2], st));
-    {
-        const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
-        // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
-        const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
-        for (int cls = 0; cls < kFusedClasses; cls++) {
-            const size_t off = class_off[cls], n = class_off[cls + 1] - off;
-            if (!n) continue;
-            FusedScratch fsc = fs;
-            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
-            fsc.cand_cnt = fs.cand_cnt + off;
-            const bool tp = cls < 6;
-            launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
-                              ctx->peaks.as<unsigned long long>(),
-                              cls >= 14 ? 6 : cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
-                              cls >= 14 ? cls - 14 : cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
-        }
-    }
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
     ctx->comb_off = comb_span.off;
     ctx->comb_n = comb_span.n;
