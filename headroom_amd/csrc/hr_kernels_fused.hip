@@ -1,8 +1,10 @@
 // hr_kernels_fused.hip -- the hot kernel: K-weighting + hop energies + true peak in ONE read of the PCM.
-// Stereo f32 interleaved input, libswresample-style true peak (HR_TP_SWR192K).
+// Stereo f32 (or s16, or packed s24) interleaved input; the true peak of either bank (libswresample's to 192 kHz,
+// BS.1770 Annex 2).
 //
-// Decomposition.  A wave owns 64 consecutive interior hops (100 ms each) of one track, one hop ("row") per
-// lane; the 64 rows advance in lock step, 16 frames (one 128-byte piece per row) per step.
+// Decomposition.  A wave owns up to 64 consecutive rows of one track, one row per lane; a row is a hop (100 ms) or a
+// whole fraction of one (FusedItem::row_len: the host picks it per launch and track, run_measure).  The 64 rows advance
+// in lock step, 16 frames (one 128-byte piece per row) per step.
 //   * HBM -> LDS: eight global_load_lds_dwordx4 per step move the 64 pieces (8 KiB) with every 128-byte
 //     piece read by 8 adjacent lanes (full cache lines), no VGPR staging.  The LDS image is lane-linear, so
 //     the bank swizzle is applied on the SOURCE chunk index (chunk ^ ((row>>1)&7)) and undone by the reader:
@@ -24,8 +26,10 @@
 //     the reported peak is the exact f64 maximum over all outputs: bit-identical to the generic kernel and
 //     to the oracle.  A wave whose list overflows flags its track, which then takes the generic kernel.
 //
-// Rows cover hops 0 .. n_hops-2; the last hop and the ragged tail of every track (1/1800 of a 3-minute
-// track) go through the bounds-checked generic kernels, so this kernel needs no bounds checks at all.
+// Rows cover the whole track where the stream ends with it: the final hop and the ragged tail behind it are rows too,
+// kept honest behind wave-uniform branches in the last steps of the one wave that holds them ("the track's LAST rows"
+// below); the few positions behind the last screened tile go through the bounds-checked generic kernel.  Everywhere
+// else this kernel needs no bounds checks at all.
 //
 // Replaces FFmpeg f_ebur128.c FILTER()/i400 accumulation and swr_convert + fabs max (reached from
 // src/analyzer.rs:253-267); SURVEY.md Appendix A.2 / A.4.
