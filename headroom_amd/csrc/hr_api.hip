@@ -102,10 +102,10 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ebu_edges, ln_energy, ln_bounds, unit_tap;
 
     // workspace (grow-only)
-    DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, comb_items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
-    std::vector<WorkItem> h_items;
+    std::vector<WorkItem> h_items, h_comb_items;
     std::vector<FusedItem> h_fitems;
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<uint64_t> h_fend;     // ... which screened the positions in front of this one (redo_overflowed_peaks)
@@ -123,7 +123,7 @@ struct hr_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float last_total_ms = 0, last_main_ms = 0;
 
-    size_t comb_off = 0, comb_n = 0;  // combine work items of the last run_measure
+    size_t comb_n = 0;  // combine work items of the last run_measure (comb_items_d)
 
     // state of an open time shard (hr_shard_pass1 .. hr_shard_pass2)
     bool shard_open = false;
@@ -134,7 +134,7 @@ struct hr_ctx {
     // every grow-only workspace buffer (not the device tables)
     std::vector<DevBuf *> workspace()
     {
-        return {&widened, &resampled, &parents_d, &counters, &gate_items, &gate_parts, &st_hist, &tracks_d, &items_d, &fitems_d,
+        return {&widened, &resampled, &parents_d, &counters, &gate_items, &gate_parts, &st_hist, &tracks_d, &items_d, &comb_items_d, &fitems_d,
                 &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos};
     }
 };
@@ -543,40 +543,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         HIPCHK(hipMemsetAsync(ctx->tpb.p, 0, nt * kMaxCh * 2 * sizeof(unsigned), st));
         HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
     }
-    ctx->h_ftp.assign(ftp.begin(), ftp.end());
-
-    HIPCHK(hipEventRecord(ctx->ev[0], st));
-    if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
-    // fork point for the generic kernels on the side stream: everything they and the fused kernel share (descriptors,
-    // rate tables, the zeroed peak slots) has been issued on st before it
-    hipStream_t tail_st = ctx->serial_tail ? st : ctx->side;
-    HIPCHK(hipEventRecord(ctx->ev_fork, st));
-    HIPCHK(hipEventRecord(ctx->ev[2], st));
-    {
-        const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
-        // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
-        const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
-        for (int cls = 0; cls < kFusedClasses; cls++) {
-            const size_t off = class_off[cls], n = class_off[cls + 1] - off;
-            if (!n) continue;
-            FusedScratch fsc = fs;
-            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
-            fsc.cand_cnt = fs.cand_cnt + off;
-            const bool tp = cls < 6;
-            launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
-                              ctx->peaks.as<unsigned long long>(),
-                              cls >= 14 ? 6 : cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
-                              cls >= 14 ? cls - 14 : cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
-        }
-    }
-    HIPCHK(hipEventRecord(ctx->ev[3], st));
-    if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
-    // The fused kernel is on its way: the host builds the work items of the generic kernels beside it ([fmt] hop items,
-    // combine items, [fmt][kind] peak items -- one upload, on the side stream, where their kernels follow it)
+    // work items of the generic kernels that run beside the fused kernel: [fmt] hop items, [fmt][kind] peak items
     std::vector<WorkItem> &items = ctx->h_items;
     items.clear();
     struct Span { size_t off, n; };
-    Span hop_span[5], pk_span[5][2], comb_span;
+    Span hop_span[5], pk_span[5][2];
     for (int f = 0; f < 5; f++) {
         hop_span[f].off = items.size();
         for (size_t i = 0; i < nt; i++) {
@@ -596,14 +567,6 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                 for (uint32_t c = 0; c < g.descs[i].ch; c++) items.push_back({static_cast<uint32_t>(i), c, g.descs[i].n_hops - 1});
         tail_span[f].n = items.size() - tail_span[f].off;
     }
-    comb_span.off = items.size();
-    for (size_t i = 0; i < nt; i++) {
-        const auto &d = g.descs[i];
-        if (d.role == 1) continue;
-        const uint64_t pairs = (d.n_hops + (d.blk_first < 0 ? kPreBlk : 0)) * d.ch;
-        for (uint64_t p = 0; p < pairs; p += 256) items.push_back({static_cast<uint32_t>(i), 0, p});
-    }
-    comb_span.n = items.size() - comb_span.off;
     // kind 0 = the configured interpolator, kind 1 = sample peak (192 kHz input: libswresample does not
     // resample, so f_ebur128's "true peak" is the sample peak; BS.1770 asks for no oversampling there)
     for (int f = 0; f < 5; f++)
@@ -626,10 +589,19 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             pk_span[f][kind].n = items.size() - pk_span[f][kind].off;
         }
     if (!items.empty()) {
-        rc = upload(ctx->items_d, items.data(), items.size() * sizeof(WorkItem), tail_st);
+        rc = upload(ctx->items_d, items.data(), items.size() * sizeof(WorkItem), st);
         if (rc) return rc;
     }
     const WorkItem *di = ctx->items_d.as<WorkItem>();
+    ctx->h_ftp.assign(ftp.begin(), ftp.end());
+
+    HIPCHK(hipEventRecord(ctx->ev[0], st));
+    if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
+    // fork point for the generic kernels on the side stream: everything they and the fused kernel share (descriptors,
+    // rate tables, the zeroed peak slots) has been issued on st before it
+    hipStream_t tail_st = ctx->serial_tail ? st : ctx->side;
+    HIPCHK(hipEventRecord(ctx->ev_fork, st));
+    if (!ctx->serial_tail) HIPCHK(hipStreamWaitEvent(tail_st, ctx->ev_fork, 0));
 
     for (int f = 0; f < 5; f++)
         launch_hop_zero_state(f, dt, dr, di + hop_span[f].off, static_cast<uint32_t>(hop_span[f].n), ctx->recs.as<HopRec>(), tail_st);
@@ -646,11 +618,43 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             }
     }
     HIPCHK(hipEventRecord(ctx->ev_join, tail_st));
+    HIPCHK(hipEventRecord(ctx->ev[2], st));
+    {
+        const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
+        // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
+        const int v0 = ctx->ablate & 3, dbg = ctx->ablate >> 4;
+        for (int cls = 0; cls < kFusedClasses; cls++) {
+            const size_t off = class_off[cls], n = class_off[cls + 1] - off;
+            if (!n) continue;
+            FusedScratch fsc = fs;
+            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
+            fsc.cand_cnt = fs.cand_cnt + off;
+            const bool tp = cls < 6;
+            launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
+                              ctx->peaks.as<unsigned long long>(),
+                              cls >= 14 ? 6 : cls >= 8 ? 5 : tp ? (v0 == 0 && dbg == 0 && ctx->split ? 4 : v0) : (v0 == 3 ? 3 : 1),
+                              cls >= 14 ? cls - 14 : cls >= 8 ? cls - 8 : cls, cls == 7 ? (dbg | 64) : dbg, st);
+        }
+    }
+    HIPCHK(hipEventRecord(ctx->ev[3], st));
+    // The fused kernel is on its way: the host builds the combine kernel's work items beside it (one per 256 (hop, channel)
+    // pairs: the bulk of the generic items); their upload queues behind the fused kernel, where the combine kernel follows
+    std::vector<WorkItem> &citems = ctx->h_comb_items;
+    citems.clear();
+    for (size_t i = 0; i < nt; i++) {
+        const auto &d = g.descs[i];
+        if (d.role == 1) continue;
+        const uint64_t pairs = (d.n_hops + (d.blk_first < 0 ? kPreBlk : 0)) * d.ch;
+        for (uint64_t p = 0; p < pairs; p += 256) citems.push_back({static_cast<uint32_t>(i), 0, p});
+    }
+    if (!citems.empty()) {
+        rc = upload(ctx->comb_items_d, citems.data(), citems.size() * sizeof(WorkItem), st);
+        if (rc) return rc;
+    }
     HIPCHK(hipStreamWaitEvent(st, ctx->ev_join, 0));
-    ctx->comb_off = comb_span.off;
-    ctx->comb_n = comb_span.n;
+    ctx->comb_n = citems.size();
     if (do_combine)
-        launch_hop_combine(dt, dr, di + comb_span.off, static_cast<uint32_t>(comb_span.n), ctx->recs.as<HopRec>(),
+        launch_hop_combine(dt, dr, ctx->comb_items_d.as<WorkItem>(), static_cast<uint32_t>(citems.size()), ctx->recs.as<HopRec>(),
                            ctx->hop_sums.as<double>(), std::any_of(sub_p.begin(), sub_p.end(), [](uint32_t p) { return p > 1; }), st);
     if (do_combine && !g.parents.empty()) {
         rc = upload(ctx->parents_d, g.parents.data(), g.parents.size() * sizeof(uint32_t), st);
@@ -1015,7 +1019,7 @@ void hr_destroy(hr_ctx *ctx)
     (void)hipSetDevice(ctx->cfg.device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ebu_edges, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
-                      &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
+                      &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->comb_items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
@@ -1343,7 +1347,7 @@ try {
     }
     int rc = upload(ctx->tracks_d, g.descs.data(), g.descs.size() * sizeof(TrackDesc), st);  // (st_pre may have changed)
     if (rc) return rc;
-    launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->items_d.as<WorkItem>() + ctx->comb_off,
+    launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->comb_items_d.as<WorkItem>(),
                        static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), false, st);
     rc = run_gating(ctx, g, false, true);
     if (rc) return rc;
