@@ -50,7 +50,7 @@
 #define HR_DBG(dbg, bit) false
 #if defined(HR_EXP_NO_FRAGS) || defined(HR_EXP_NO_MFMA) || defined(HR_EXP_NO_KW) || defined(HR_EXP_NO_REDUCE) || \
     defined(HR_EXP_NO_AF) || defined(HR_EXP_NO_BARRIER) || defined(HR_EXP_NO_VMWAIT) || defined(HR_EXP_PRIO) || \
-    defined(HR_EXP_NO_Q) || defined(HR_EXP_NO_COEF_DMA) || defined(HR_EXP_NO_CAND) || defined(HR_EXP_NO_BOUNDS) || defined(HR_EXP_NO_MFMA2) || defined(HR_EXP_PCM_AUX) || defined(HR_EXP_COEF_PAT0)
+    defined(HR_EXP_NO_Q) || defined(HR_EXP_NO_COEF_DMA) || defined(HR_EXP_NO_CAND) || defined(HR_EXP_NO_BOUNDS) || defined(HR_EXP_NO_MFMA2) || defined(HR_EXP_PCM_AUX) || defined(HR_EXP_COEF_PAT0) || defined(HR_EXP_NO_RESIDENT)
 #error "HR_EXP_* switches need -DHR_EXPERIMENTS"
 #endif
 #endif
@@ -71,7 +71,10 @@ typedef const __attribute__((address_space(4))) uint4v *cuint4v_p;
 //   2 x 9 KiB   coefficient tiles of the tile being screened / the next one, shared by the four waves
 //   2 x 1 KiB   carry-table slice of this step / the next one, shared
 constexpr int kPieceLds = 8192, kCoefLds = 9 * 1024, kCarryLds = 1024;
-constexpr int kGroupLds = kFusedWaves * kPieceLds + 2 * kCoefLds + 2 * kCarryLds;
+// (the coefficient area of k_fused_f32s: the two halves above, or -- rates with ONE tile pattern of at most two blocks: 48,
+// 96, 32 kHz ..., the BS.1770 bank -- the tile's three rotations, resident for the whole kernel, and a block of zeros)
+constexpr int kCoefArea = 24 * 1024;
+constexpr int kGroupLds = kFusedWaves * kPieceLds + kCoefArea + 2 * kCarryLds;
 constexpr int kFmtF32 = 0, kFmtS16 = 1, kFmtS24 = 2;  // HR_FMT_F32, HR_FMT_S16, HR_FMT_S24 of include/headroom_hip.h
 constexpr int kCandCap = 512;              // candidate slots per wave
 
@@ -360,8 +363,17 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     constexpr int LPP = PB / 16;                // lanes per piece
     const char *wave_base = static_cast<const char *>(t.pcm) + it.frame0 * static_cast<unsigned long long>(FB);
     char *lbuf = smem + wave * kPieceLds;
-    char *abuf = smem + kFusedWaves * kPieceLds;    // [2][9 KiB]: step k reads half k&1
-    char *gbuf = abuf + 2 * kCoefLds;     // [2][1 KiB]: step k reads half k&1
+    char *abuf = smem + kFusedWaves * kPieceLds;    // [2][9 KiB]: step k reads half k&1 (or the resident rotations, below)
+    char *gbuf = abuf + kCoefArea;        // [2][1 KiB]: step k reads half k&1
+    // One tile pattern (every tile of the rate has the same coefficients): nothing to stream.  The tile's three rotations
+    // (step k reads rotation k mod 3: chunk ks sits where the fragment slot of piece k-2+ks expects it) are loaded once,
+    // and step 0, which screens a tile that does not exist, reads a block of zeros behind them.
+    constexpr int RS = 3 * MT * 1024;  // one rotation
+#ifdef HR_EXP_NO_RESIDENT
+    const bool resident = false;
+#else
+    const bool resident = DO_TP && MT <= 2 && r.tp_np == 1;
+#endif
     const char *gsrc = reinterpret_cast<const char *>(r.g);  // 512 B (16 frames x 4 doubles) per step
     const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
     const int T_full = static_cast<int>(hop / 16), rem = static_cast<int>(hop % 16);
@@ -420,7 +432,20 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
     // the coefficient area starts as zeros: step 0 screens a tile that does not exist and must find nothing
     if constexpr (DO_TP) {
 #pragma unroll
-        for (int i = 0; i < 3 * MT; i++) *reinterpret_cast<uint4v *>(abuf + i * 1024 + lane * 16) = uint4v{0, 0, 0, 0};  // (all four waves write the same zeros)
+        for (int i = 0; i < 3 * MT; i++) *reinterpret_cast<uint4v *>(abuf + (resident ? 3 * RS : 0) + i * 1024 + lane * 16) = uint4v{0, 0, 0, 0};  // (all four waves write the same zeros)
+        if constexpr (MT <= 2) {
+            if (resident) {
+                const char *asrc = reinterpret_cast<const char *>(r.tp_atab);
+#pragma unroll
+                for (int V = 0; V < 3; V++)
+#pragma unroll
+                    for (int mt = 0; mt < MT; mt++)
+#pragma unroll
+                        for (int ksx = 0; ksx < 3; ksx++)
+                            if (((V * 3 * MT + mt * 3 + ksx) % kFusedWaves) == wave)
+                                dma16(asrc + (mt * 3 + ksx) * 1024, lane16, abuf + V * RS + (mt * 3 + (V + 1 + ksx) % 3) * 1024);
+            }
+        }
     }
 
     // ---- prologue: the 16 frames in front of the row (FIR window of tile 0, filter input history)
@@ -687,7 +712,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
             }
             if constexpr (DO_TP) {
 #ifndef HR_EXP_NO_COEF_DMA
-                issue_coeff(pat, k, KK);
+                if (!resident) issue_coeff(pat, k, KK);
 #endif
                 pat = pat + 1 == NP ? 0 : pat + 1;
             }
@@ -744,6 +769,8 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
 
         // ---- the hot block, branch-free so that the scheduler can run the f64 K-weighting of piece k under
         // the MFMAs of tile k-1 (pieces k-2, k-1, k): K3 screen ...
+        // where this step's coefficient tile sits in the coefficient area
+        const unsigned coef_off = resident ? static_cast<unsigned>(k == 0 ? 3 : KK) * RS : static_cast<unsigned>(k & 1) * kCoefLds;
         float m0[MT][2][2];
         auto screen = [&]() {
             if constexpr (DO_TP) {
@@ -751,7 +778,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
                 for (int mt = 0; mt < MT; mt++) {
                     uint4v af[3];
 #pragma unroll
-                    for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + (k & 1) * kCoefLds + (mt * 3 + k3) * 1024 + lane * 16);
+                    for (int k3 = 0; k3 < 3; k3++) af[k3] = *reinterpret_cast<const uint4v *>(abuf + coef_off + (mt * 3 + k3) * 1024 + lane * 16);
 #pragma unroll
                     for (int ch = 0; ch < 2; ch++) {
 #pragma unroll
@@ -780,7 +807,7 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
         // fetched one slice ahead.  (Without DO_TP this is just the K-weighting in eight slices.)
         auto fused_block = [&]() {
             const unsigned g_at = lds_addr(gbuf) + static_cast<unsigned>(k & 1) * kCarryLds;  // wave-uniform: broadcast reads
-            const unsigned a_at = lds_addr(abuf) + static_cast<unsigned>(k & 1) * kCoefLds + lane16;
+            const unsigned a_at = lds_addr(abuf) + coef_off + lane16;
             struct GC { uint4v r[4]; };  // rows 2c, 2c+1 of the slice: {g0 g1}, {g2 g3} each (SHORT: only {g2 g3})
             auto load_gc = [&](int c) {
                 GC o;
