@@ -884,10 +884,64 @@ __global__ void __launch_bounds__(256) k_resample_swr_tiled(const void *__restri
     }
 }
 
+// The same by phase (exact phases, step > 1: 44.1 kHz and its family).  Outputs P apart share a phase, i.e. their taps,
+// and sit `step` input frames apart: a lane takes one such "cycle" (step frames in, P outputs out), the wave walks the
+// phases, so the 32 taps of a phase are wave-uniform (scalar loads) instead of 64 different rows of the table per load
+// -- the per-thread tap rows from L2 were what the tiled kernel above cost.  The window of 64 cycles (64 * step + 32
+// doubles) sits in LDS; lanes read it `step` doubles apart (conflict-free for odd steps).  Same FMA order, same bits.
+constexpr int kRsCycles = 64;
+template <int FMT>
+__global__ void __launch_bounds__(256) k_resample_swr_phase(const void *__restrict__ src, int64_t N, int C, int P, int step,
+                                                            const double *__restrict__ taps, double *__restrict__ dst, int64_t n_total)
+{
+    extern __shared__ double xs_dyn[];  // kRsCycles * step + kSwrTaps
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t cyc0 = static_cast<int64_t>(blockIdx.x) * kRsCycles;
+    const int64_t f0 = cyc0 * step;  // first frame of the tile: phase 0 of the pattern
+    const int span = kRsCycles * step + kSwrTaps - 1;
+    for (int c = 0; c < C; c++) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < span; i += 256) {
+            int64_t k = f0 - 15 + i;
+            if (k < 0) k = -k;
+            if (k >= N) k = 2 * N - 1 - k;
+            xs_dyn[i] = (k < 0 || k >= N) ? 0.0 : ld_sample<FMT>(src, static_cast<uint64_t>(k) * C + c);
+        }
+        __syncthreads();
+        const int64_t nbase = (cyc0 + lane) * P;  // this lane's first output
+        const double *x0 = xs_dyn + lane * step;
+        for (int ph = wave; ph < P; ph += 4) {    // (wave-uniform)
+            const int num = ph * step, u = num / P, tp = num - u * P;  // position within the cycle, phase of the bank
+            const double *__restrict__ f = taps + static_cast<size_t>(tp) * kSwrTaps;
+            const double *x = x0 + u;
+            double val = 0.0;
+#pragma unroll
+            for (int i = 0; i < kSwrTaps; i++) val = fma(x[i], f[i], val);
+            const int64_t n = nbase + ph;
+            if (n < n_total) dst[n * C + c] = val;
+        }
+    }
+}
+
 void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, int S, uint32_t frac_scale,
                          double inv_src_incr, const double *taps, double *dst, hipStream_t st)
 {
     if (!frames) return;
+    if (S == 1 && step > 1 && step <= 160 && phases >= 4) {
+        const uint64_t cycles = (frames + static_cast<uint64_t>(step) - 1) / static_cast<uint64_t>(step);
+        const uint64_t n_total = (frames * static_cast<uint64_t>(phases) + static_cast<uint64_t>(step) - 1) / static_cast<uint64_t>(step);
+        const uint64_t tiles = (cycles + kRsCycles - 1) / kRsCycles;
+        const size_t lds = (static_cast<size_t>(kRsCycles) * step + kSwrTaps) * sizeof(double);
+        if (tiles < 0x7fffffffull) {
+            const dim3 grid(static_cast<uint32_t>(tiles));
+#define HR_RP_CASE(F) case F: \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_resample_swr_phase<F>), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)); \
+            k_resample_swr_phase<F><<<grid, dim3(256), lds, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, taps, dst, static_cast<int64_t>(n_total)); break;
+            switch (fmt) { HR_RP_CASE(0) HR_RP_CASE(1) HR_RP_CASE(2) HR_RP_CASE(3) default: HR_RP_CASE(4) }
+#undef HR_RP_CASE
+            return;
+        }
+    }
     // (a tile's phase numerators stay below 256 * phases + step)
     if (S == 1 && 256ull * static_cast<uint64_t>(phases) + static_cast<uint64_t>(step) < 0x7fffffffull && (frames + 255) / 256 < 0x7fffffffull) {
         const dim3 grid(static_cast<uint32_t>((frames + 255) / 256));
