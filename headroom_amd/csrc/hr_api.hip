@@ -109,6 +109,7 @@ struct hr_ctx {
     std::vector<FusedItem> h_fitems;
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<uint64_t> h_fend;     // ... which screened the positions in front of this one (redo_overflowed_peaks)
+    std::vector<unsigned> h_ovf, h_cand_cnt;  // redo_overflowed_peaks: the flags of the last launch, read back
     std::vector<WorkItem> h_ovf_items, h_gate_items;
     bool no_s16_direct = false;  // HR_NO_S16_DIRECT=1: stereo s16 is widened into f32 planes first, as before
     // the next three are set only by the experiments library (-DHR_EXPERIMENTS, make exp); always false / 0 in the shipped one
@@ -772,56 +773,93 @@ void fill_result(const hr_ctx *ctx, const TrackOut &o, const unsigned long long 
     r->status = HR_OK;
 }
 
-// A wave of the fused kernel ran out of candidate slots (or met samples beyond the f16 range): the track's
-// fused positions are redone with the generic f64 kernel.  Synchronises the stream.  Expected never to
-// trigger on audio; it keeps the exactness guarantee unconditional.
-int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
+// A wave of the fused kernel ran out of candidate slots (sustained tones: every crest is a candidate of the f16 screen), or a
+// track met samples beyond the f16 range: the positions that wave -- or that track's fused rows -- screened are redone
+// exactly by k_true_peak_rows.  Synchronises the stream (the flags are read on the host).  Rare on music (a clipped or
+// limited master lists a few dozen groups per wave); it keeps the exactness guarantee unconditional.
+// Two halves, so that a caller can read the flags back with its results and synchronise once: overflow_flags_fetch queues
+// the copies of the flags, overflow_redo (after the stream has been synchronised) launches the redo where a flag is set
+// and says whether it did -- the caller then reads the peaks again.
+int overflow_flags_fetch(hr_ctx *ctx, Group &g)
 {
     hipStream_t st = ctx->stream;
     const size_t nt = g.descs.size();
+    ctx->h_ovf.clear();
+    ctx->h_cand_cnt.clear();
     bool any_fused = false;
     for (size_t i = 0; i < nt && i < ctx->h_ftp.size(); i++) any_fused |= ctx->h_ftp[i] != 0;
     if (!any_fused) return HR_OK;
-    std::vector<unsigned> ovf(nt);
-    HIPCHK(hipMemcpyAsync(ovf.data(), ctx->overflow.p, nt * sizeof(unsigned), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipStreamSynchronize(st));
+    ctx->h_ovf.resize(nt);
+    HIPCHK(hipMemcpyAsync(ctx->h_ovf.data(), ctx->overflow.p, nt * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    return HR_OK;
+}
+
+int overflow_redo(hr_ctx *ctx, Group &g, bool *relaunched)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nt = g.descs.size();
+    *relaunched = false;
+    std::vector<unsigned> &ovf = ctx->h_ovf, &cnt = ctx->h_cand_cnt;
+    if (ovf.size() != nt) return HR_OK;  // (no fused track in the launch)
+    const bool debug = std::getenv("HR_DEBUG") != nullptr;
+    bool any = debug, waves = debug;
+    for (unsigned o : ovf) { any |= o != 0; waves |= (o & 2u) != 0; }
+    if (!any) return HR_OK;
+    if (waves && !ctx->h_fitems.empty()) {  // which waves: their candidate counts carry kCandOverflowBit
+        cnt.resize(ctx->h_fitems.size());
+        HIPCHK(hipMemcpyAsync(cnt.data(), ctx->cand_cnt.p, cnt.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     std::vector<WorkItem> &items = ctx->h_ovf_items;
     items.clear();
+    // [first, end) of track i in items of one wave each: 64 lanes x redo_lane_frames(step) positions
+    auto add_range = [&](size_t i, uint64_t first, uint64_t end) {
+        const uint64_t per_wave = 64ull * redo_lane_frames(static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].swr_step));
+        for (uint64_t n = first; n < end; n += per_wave)
+            items.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min(per_wave, end - n)), n});
+    };
     size_t fmt_end[3];  // f32 items first, then s16, then s24
     for (int f = 0; f < 3; f++) {
-        for (size_t i = 0; i < nt; i++) {
-            if (!ctx->h_ftp[i] || !ovf[i] || g.fmts[i] != f) continue;
-            // everything the fused kernel screened
-            const uint64_t end = ctx->h_fend[i];
-            for (uint64_t n = 0; n < end; n += kPeakSpan) items.push_back({static_cast<uint32_t>(i), 0, n});
+        // whole tracks: everything the fused kernel screened
+        for (size_t i = 0; i < nt; i++)
+            if (ctx->h_ftp[i] && (ovf[i] & 1u) && g.fmts[i] == f) add_range(i, 0, ctx->h_fend[i]);
+        // single waves (their rows start at multiples of the resampler's input step: run_measure)
+        for (size_t w = 0; w < cnt.size(); w++) {
+            const FusedItem &it = ctx->h_fitems[w];
+            if (!(cnt[w] & kCandOverflowBit) || !it.n_rows || !ctx->h_ftp[it.track] || (ovf[it.track] & 1u) || g.fmts[it.track] != f) continue;
+            add_range(it.track, it.frame0, std::min<uint64_t>(it.frame0 + static_cast<uint64_t>(it.n_rows) * it.row_len, ctx->h_fend[it.track]));
         }
         fmt_end[f] = items.size();
     }
     if (std::getenv("HR_DEBUG")) {
-        std::vector<unsigned> cnt(ctx->h_fitems.size());
-        (void)hipMemcpy(cnt.data(), ctx->cand_cnt.p, cnt.size() * sizeof(unsigned), hipMemcpyDeviceToHost);
         unsigned long long tot = 0, mx = 0, full = 0, novf = 0;
-        for (unsigned c : cnt) { tot += c; mx = std::max<unsigned long long>(mx, c); full += c >= 512; }
-        for (unsigned o : ovf) novf += o != 0;
-        for (size_t i = 0, shown = 0; i < cnt.size() && shown < 12; i++)
-            if (cnt[i] >= 512) { std::fprintf(stderr, "  full list: track %u first_hop %llu rows %u\n", ctx->h_fitems[i].track, (unsigned long long)ctx->h_fitems[i].first_hop, ctx->h_fitems[i].n_rows); shown++; }
-        for (size_t i = 0; i < 29 && i < cnt.size(); i++) std::fprintf(stderr, " %u", cnt[i]);
-        std::fprintf(stderr, "\n");
-        std::fprintf(stderr, "headroom_hip: fused waves %zu, candidates total %llu (mean %.1f, max %llu, full lists %llu), overflowed tracks %llu of %zu\n",
-                     cnt.size(), tot, cnt.empty() ? 0.0 : double(tot) / cnt.size(), mx, full, novf, nt);
+        for (unsigned c : cnt) { const unsigned n = c & ~kCandOverflowBit; tot += n; mx = std::max<unsigned long long>(mx, n); full += (c & kCandOverflowBit) != 0; }
+        for (unsigned o : ovf) novf += (o & 1u) != 0;
+        std::fprintf(stderr, "headroom_hip: fused waves %zu, candidates total %llu (mean %.1f, max %llu, overflowed lists %llu), tracks beyond the f16 range %llu of %zu, redo items %zu\n",
+                     cnt.size(), tot, cnt.empty() ? 0.0 : double(tot) / cnt.size(), mx, full, novf, nt, items.size());
     }
     if (items.empty()) return HR_OK;
-    // the last item of a track may reach a little past `end`: those positions are redone too, harmlessly
     int rc = upload(ctx->ovf_items, items.data(), items.size() * sizeof(WorkItem), st);
     if (rc) return rc;
     for (int f = 0; f < 3; f++) {
         const size_t b = f ? fmt_end[f - 1] : 0;
-        launch_true_peak_generic(f, HR_TP_SWR192K, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(),
-                                 ctx->ovf_items.as<WorkItem>() + b, static_cast<uint32_t>(fmt_end[f] - b),
-                                 kPeakSpan, ctx->peaks.as<unsigned long long>(), st);
+        launch_true_peak_rows(f, ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->ovf_items.as<WorkItem>() + b,
+                              static_cast<uint32_t>(fmt_end[f] - b), ctx->peaks.as<unsigned long long>(), st);
     }
     HIPCHK(hipGetLastError());
+    *relaunched = true;
     return HR_OK;
+}
+
+// (both halves at once, for callers that have no results to read in the same breath; synchronises the stream)
+int redo_overflowed_peaks(hr_ctx *ctx, Group &g)
+{
+    int rc = overflow_flags_fetch(ctx, g);
+    if (rc) return rc;
+    if (ctx->h_ovf.empty()) return HR_OK;
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    bool relaunched = false;
+    return overflow_redo(ctx, g, &relaunched);
 }
 
 // Every f32 / s16 / s24 track that is not already stereo f32 is split on the device into stereo f32 planes (exactly)
@@ -949,7 +987,8 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     rc = run_gating(ctx, g, true);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
-    rc = redo_overflowed_peaks(ctx, g);
+    // the screen's overflow flags come back with the results: one synchronisation in the common case (no flag set)
+    rc = overflow_flags_fetch(ctx, g);
     if (rc) return rc;
     const size_t nt = g.descs.size();
     std::vector<TrackOut> outs(nt);
@@ -957,6 +996,13 @@ int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t>
     HIPCHK(hipMemcpyAsync(outs.data(), ctx->outs.p, nt * sizeof(TrackOut), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
+    bool relaunched = false;
+    rc = overflow_redo(ctx, g, &relaunched);
+    if (rc) return rc;
+    if (relaunched) {
+        HIPCHK(hipMemcpyAsync(pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+    }
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_total_ms += ms;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_main_ms += ms;

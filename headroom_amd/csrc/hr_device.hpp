@@ -19,6 +19,13 @@ constexpr int kLnBins = 1000;
 #define HR_WG_WAVES 4
 #endif
 constexpr int kFusedWaves = HR_WG_WAVES;
+// k_true_peak_rows (the exact redo of what a fused wave could not list): a lane walks this many consecutive positions, a
+// whole number of resampler cycles (`step` input frames), so that every lane of a wave is at the same phase of the bank
+#ifdef __HIP__
+__host__ __device__
+#endif
+inline uint32_t redo_lane_frames(uint32_t step) { return step * ((128u + step - 1u) / step); }
+constexpr uint32_t kCandOverflowBit = 0x80000000u;  // in a wave's candidate count: its list ran out of slots
 constexpr uint32_t kGateChunk = 16384;  // 400 ms blocks (and 3 s windows) per gating workgroup: a 3-minute track is one chunk
 
 // what one gating chunk hands to the per-track finalisation (summed there in chunk order: reproducible)

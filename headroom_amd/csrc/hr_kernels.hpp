@@ -50,9 +50,15 @@ struct FusedScratch {
     void *cands;         // fused_cand_bytes(n_items): per-wave candidate lists
     unsigned *cand_cnt;  // [n_items]
     unsigned *tpb;       // [n_tracks][kMaxCh][2]: final lower bound / sample peak per channel (float bits), zeroed per call
-    unsigned *overflow;  // [n_tracks]: a wave's list overflowed -> the track's peak must be redone generically, zeroed per call
+    unsigned *overflow;  // [n_tracks], zeroed per call: bit 0 = samples beyond the f16 range (the track's fused positions are redone
+                         // exactly), bit 1 = some wave's list overflowed (those waves are: kCandOverflowBit in their counts)
 };
 size_t fused_cand_bytes(uint32_t n_items);
+// Exact true peak (the context's bank, exact phase counts only) of ranges of stereo f32 / s16 / s24 tracks: an item is one
+// wave, item.first its first position (a multiple of the resampler's input step), item.pad its positions
+// (<= 64 * redo_lane_frames(step)).  The redo of fused waves whose candidate lists overflowed.
+void launch_true_peak_rows(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
+                           unsigned long long *peaks, hipStream_t st);
 // All items of one launch share a true-peak class (the kernel is specialised on the tile shape of the rate).
 int fused_tp_class(int tp_mt, int tp_last_rows);
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,

@@ -1051,9 +1051,13 @@ __global__ void __launch_bounds__(64 * kFusedWaves, 8 / kFusedWaves) k_fused_f32
             Af[c] = wave_max_f32(alb[c]);
             lb[c] = fmaxf(lb[c], fmaxf(passthru0 ? Sf[c] : 0.0f, Af[c] - fmaf(kScreenRel, fmaxf(Sf[c], S_x[c]), kScreenAbs)));
         }
-        if (lane == 0) cand_cnt[item_idx] = n_cand < kCandCap ? n_cand : kCandCap;
+        // A list that ran out of slots marks the WAVE (the host has k_true_peak_rows redo this wave's positions exactly, the
+        // listed groups are still refined); samples beyond the f16 range void the screen's bounds for the whole track.
+        // (the track's flag word tells the host that some wave's count carries the bit: it reads the counts only then)
+        if (lane == 0) cand_cnt[item_idx] = n_cand <= kCandCap ? n_cand : (kCandCap | (n_rows > 0 ? kCandOverflowBit : 0u));
         if (lane == 0 && n_rows > 0) {  // (padding waves list nothing and report nothing)
-            if (n_cand > kCandCap || fmaxf(Sf[0], S_x[0]) >= kF16Safe || fmaxf(Sf[1], S_x[1]) >= kF16Safe) overflow[it.track] = 1u;
+            if (n_cand > kCandCap) atomicOr(&overflow[it.track], 2u);
+            if (fmaxf(Sf[0], S_x[0]) >= kF16Safe || fmaxf(Sf[1], S_x[1]) >= kF16Safe) atomicOr(&overflow[it.track], 1u);
 #pragma unroll
             for (int c = 0; c < 2; c++) {
                 // non-negative floats order like their bit patterns
@@ -1496,6 +1500,7 @@ __global__ void __launch_bounds__(256) k_refine_cands(const TrackDesc *__restric
 {
     const uint32_t item = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (item >= n_items) return;
+    if (cand_cnt[item] & kCandOverflowBit) return;  // the list ran out of slots: k_true_peak_rows redoes the whole wave
     const unsigned n = cand_cnt[item];
     const int lane = threadIdx.x & 63;
     if (static_cast<unsigned>(lane) >= n) return;
@@ -1528,6 +1533,145 @@ __global__ void __launch_bounds__(256) k_refine_cands(const TrackDesc *__restric
     }
     if (best0 > 0.0) atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + 0], static_cast<unsigned long long>(__double_as_longlong(best0)));
     if (best1 > 0.0) atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + 1], static_cast<unsigned long long>(__double_as_longlong(best1)));
+}
+
+// ---- k_true_peak_rows: the exact true peak of whole ranges of a stereo track, fast --------------------------------------
+// What redoes the positions of a fused wave whose candidate list ran out of slots (sustained tones, test signals: every
+// crest is a candidate of the f16 screen), or of a whole track whose samples leave the f16 range.  The generic kernel
+// (one thread per position, every thread its own row of the tap table from L2) takes 2.5 ms per 3-minute track; here
+// the 32 taps of an output are wave-uniform and arrive through scalar loads as FMA operands, and the 32-frame window
+// of a channel slides through registers, so an output costs its 32 f64 FMAs and little else.
+//   * A lane owns redo_lane_frames(step) consecutive positions -- whole resampler cycles, so that all 64 lanes are at the
+//     same phase of the bank at every step -- and a wave 64 such runs (item.first, a multiple of `step` frames; item.pad
+//     positions count from there), one wave per channel.  The window of position p (frames p-15 .. p+16) sits in 32
+//     registers, frame f in register (f - p0 + 15) mod 32: the loop is unrolled 32 positions deep, so every index is static.
+//   * PCM arrives 16 frames per lane and load (f32 / s16, range inside the track: FAST), one load ahead; at the
+//     track's edges and for packed s24 (FAST = false) frame by frame through fetch_f32s (reflection, halos, zeros).
+//   * Same FMA chain as exact_output / k_true_peak_swr / the oracle (taps 0..31 in order, from 0.0): same bits.
+// Replaces libswresample's swr_convert + f_ebur128's fabs max for those positions (reached from src/analyzer.rs:253-267).
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
+
+// frames f0 .. f0+15 of channel c
+template <int INF, bool FAST>
+__device__ __forceinline__ void tp_rows_chunk(const TrackDesc &t, int c, int64_t f0, float (&dst)[16])
+{
+    if constexpr (FAST && INF == 0) {
+        const f4u *p = reinterpret_cast<const f4u *>(static_cast<const char *>(t.pcm) + f0 * 8);
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const f4u v = p[q];
+            dst[2 * q] = c ? v[1] : v[0];
+            dst[2 * q + 1] = c ? v[3] : v[2];
+        }
+    } else if constexpr (FAST && INF == 1) {
+        constexpr float sc = 1.0f / 32768.0f;
+        const u4u *p = reinterpret_cast<const u4u *>(static_cast<const char *>(t.pcm) + f0 * 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const u4u v = p[q];
+#pragma unroll
+            for (int e = 0; e < 4; e++)  // (one dword per frame: left in the low half)
+                dst[4 * q + e] = static_cast<float>(c ? static_cast<int>(v[e]) >> 16 : static_cast<int>(v[e] << 16) >> 16) * sc;
+        }
+    } else {
+        // (every sample of these formats, and of a neighbour shard's halo, is an f32 value: nothing is rounded here)
+#pragma unroll
+        for (int e = 0; e < 16; e++) dst[e] = static_cast<float>(fetch_f32s(t, c, f0 + e));
+    }
+}
+
+template <int INF, bool FAST>
+__device__ __forceinline__ double tp_rows_body(const TrackDesc &t, int c, cdouble_p taps, int P, int step, int K, int64_t p0,
+                                               int lane_lim)
+{
+    double w[32], m = 0.0;
+    float ca[16], cb[16];
+    tp_rows_chunk<INF, FAST>(t, c, p0 - 16, ca);
+    tp_rows_chunk<INF, FAST>(t, c, p0, cb);
+#pragma unroll
+    for (int j = 0; j < 15; j++) w[j] = static_cast<double>(ca[j + 1]);
+#pragma unroll
+    for (int j = 15; j < 31; j++) w[j] = static_cast<double>(cb[j - 15]);
+    w[31] = 0.0;
+    tp_rows_chunk<INF, FAST>(t, c, p0 + 16, ca);  // frames p0+16 .. p0+31: what positions 0 .. 15 bring into the window
+    int d = 0;                                    // phase units of the next output beyond the current position (wave-uniform)
+    for (int b = 0; b < K; b += 32) {
+        tp_rows_chunk<INF, FAST>(t, c, p0 + b + 32, cb);  // for positions b+16 .. b+31
+        // position b + u; false once the lane's run is over (wave-uniform).  u is a compile-time constant, so every
+        // window index below is one too.
+        auto position = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            const int i = b + u;
+            if (i >= K) return false;
+            if constexpr (u == 16) tp_rows_chunk<INF, FAST>(t, c, p0 + b + 48, ca);  // for positions b+32 .. b+47
+            w[(u + 31) & 31] = static_cast<double>(u < 16 ? ca[u & 15] : cb[u & 15]);  // frame p0 + i + 16
+            double mp = 0.0;
+            while (d < P) {  // the outputs that sit at this position: phase d of the bank
+                const cdouble_p f = taps + static_cast<size_t>(d) * kSwrTaps;
+                double v = 0.0;
+#pragma unroll
+                for (int j = 0; j < kSwrTaps; j++) v = fma(w[(u + j) & 31], f[j], v);
+                asm volatile("" : "+v"(v));  // (every lane computes it: positions past a lane's limit are masked below, not branched around)
+                const double a = fabs(v);
+                mp = a > mp ? a : mp;
+                d += step;
+            }
+            d -= P;
+            mp = i < lane_lim ? mp : 0.0;
+            m = mp > m ? mp : m;
+            return true;
+        };
+#define HR_POS(u) if (!position(std::integral_constant<int, u>{})) break;
+#define HR_POS8(u) HR_POS(u) HR_POS(u + 1) HR_POS(u + 2) HR_POS(u + 3) HR_POS(u + 4) HR_POS(u + 5) HR_POS(u + 6) HR_POS(u + 7)
+        HR_POS8(0) HR_POS8(8) HR_POS8(16) HR_POS8(24)
+#undef HR_POS8
+#undef HR_POS
+    }
+    return m;
+}
+
+// one wave per (item, channel): blockIdx.x = 2 * item + channel; four waves per SIMD hide the scalar tap loads and the
+// FMA chain's latency
+template <int INF>
+__global__ void __launch_bounds__(64, 16) k_true_peak_rows(const TrackDesc *__restrict__ tracks, const RateDev *__restrict__ rates,
+                                                           const WorkItem *__restrict__ items, unsigned long long *__restrict__ peaks)
+{
+    const WorkItem it = items[blockIdx.x >> 1];
+    const int c = blockIdx.x & 1;
+    const TrackDesc &t = tracks[it.track];
+    const RateDev &r = rates[t.rate_idx];
+    if (!t.tp_enabled) return;
+    const int lane = threadIdx.x;
+    const int P = r.swr_phases, step = r.swr_step;
+    const int K = static_cast<int>(redo_lane_frames(static_cast<uint32_t>(step)));
+    const int64_t N = static_cast<int64_t>(t.frames);
+    const int64_t first = static_cast<int64_t>(it.first);
+    // positions with an output: up to the item's end, the track's end, and -- the resampler is not flushed -- tp_drop short of it
+    int64_t end = first + it.pad;
+    const int64_t stop = (t.stream_end ? N - t.tp_drop : N);
+    if (end > stop) end = stop;
+    const int64_t p0 = first + static_cast<int64_t>(lane) * K;
+    const int64_t lim = end - p0;
+    const int lane_lim = lim < 0 ? 0 : lim > K ? K : static_cast<int>(lim);
+    const cdouble_p taps = (cdouble_p)r.swr_taps;
+    // every frame any lane may fetch (16 in front of the first position, up to 80 behind the last) lies inside the track?
+    const bool fast = INF != 2 && first >= 16 && first + 64ll * K + 80 <= N;
+    double m = fast ? tp_rows_body<INF, true>(t, c, taps, P, step, K, p0, lane_lim)
+                    : tp_rows_body<INF, false>(t, c, taps, P, step, K, p0, lane_lim);
+    m = wave_max_f64(m);
+    if (lane == 0 && m > 0.0)
+        atomicMax(&peaks[static_cast<size_t>(it.track) * kMaxCh + c], static_cast<unsigned long long>(__double_as_longlong(m)));
+}
+
+void launch_true_peak_rows(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
+                           unsigned long long *peaks, hipStream_t st)
+{
+    if (!n_items) return;
+    const dim3 grid(2 * n_items);  // (item, channel)
+    if (fmt == kFmtS16) k_true_peak_rows<1><<<grid, dim3(64), 0, st>>>(tracks, rates, items, peaks);
+    else if (fmt == kFmtS24) k_true_peak_rows<2><<<grid, dim3(64), 0, st>>>(tracks, rates, items, peaks);
+    else k_true_peak_rows<0><<<grid, dim3(64), 0, st>>>(tracks, rates, items, peaks);
 }
 
 size_t fused_cand_bytes(uint32_t n_items) { return static_cast<size_t>(n_items) * kCandCap * sizeof(uint2); }
