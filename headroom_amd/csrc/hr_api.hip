@@ -102,7 +102,7 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ebu_edges, ln_energy, ln_bounds, unit_tap;
 
     // workspace (grow-only)
-    DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, comb_items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos;
+    DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, comb_items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos, fp_src_d, fp_items_d;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items, h_comb_items;
@@ -111,6 +111,12 @@ struct hr_ctx {
     std::vector<uint64_t> h_fend;     // ... which screened the positions in front of this one (redo_overflowed_peaks)
     std::vector<unsigned> h_ovf, h_cand_cnt;  // redo_overflowed_peaks: the flags of the last launch, read back
     std::vector<WorkItem> h_ovf_items, h_gate_items;
+    // hr_loudnorm_first_pass, while it measures a group of 192 kHz pseudo-tracks (empty otherwise): per descriptor, the
+    // source track whose leading `ext_hops` hops k_first_pass_rows measures straight from the input PCM -- run_measure
+    // launches it and gives the generic kernels only what is behind those hops
+    std::vector<FpSrc> fp_srcs;
+    std::vector<uint64_t> fp_ext_hops;
+    std::vector<FpItem> h_fp_items;
     bool no_s16_direct = false;  // HR_NO_S16_DIRECT=1: stereo s16 is widened into f32 planes first, as before
     // the next three are set only by the experiments library (-DHR_EXPERIMENTS, make exp); always false / 0 in the shipped one
     bool serial_tail = false;  // HR_SERIAL_TAIL=1 (timing experiments): tail kernels before the fused kernel, not beside it
@@ -136,7 +142,7 @@ struct hr_ctx {
     std::vector<DevBuf *> workspace()
     {
         return {&widened, &resampled, &parents_d, &counters, &gate_items, &gate_parts, &st_hist, &tracks_d, &items_d, &comb_items_d, &fitems_d,
-                &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos};
+                &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos, &fp_src_d, &fp_items_d};
     }
 };
 
@@ -562,6 +568,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         HIPCHK(hipMemsetAsync(ctx->tpb.p, 0, nt * kMaxCh * 2 * sizeof(unsigned), st));
         HIPCHK(hipMemsetAsync(ctx->overflow.p, 0, nt * sizeof(unsigned), st));
     }
+    auto ext_hops = [&](size_t i) { return i < ctx->fp_ext_hops.size() ? std::min<uint64_t>(ctx->fp_ext_hops[i], g.descs[i].n_hops) : 0; };
     // work items of the generic kernels that run beside the fused kernel: [fmt] hop items, [fmt][kind] peak items
     std::vector<WorkItem> &items = ctx->h_items;
     items.clear();
@@ -572,7 +579,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         for (size_t i = 0; i < nt; i++) {
             if (g.fmts[i] != f || g.descs[i].role == 1) continue;
             if (fkw[i]) continue;  // fused tracks: only the last hop is left, see tail_span
-            for (uint64_t h = 0; h < g.descs[i].n_hops; h += 256)
+            // (first pass: the hops k_first_pass_rows measures are not the generic kernel's)
+            for (uint64_t h = ext_hops(i); h < g.descs[i].n_hops; h += 256)
                 items.push_back({static_cast<uint32_t>(i), 0, h});
         }
         hop_span[f].n = items.size() - hop_span[f].off;
@@ -598,7 +606,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     if (plain != (kind == 1)) continue;
                     // fused tracks: the generic kernel finishes the track -- from the last hop on, or, when the last rows
                     // are fused too, from the first position of the first tile that is not screened there
-                    const uint64_t n0 = !(ftp[i] || fsp[i]) ? 0 : fend[i];
+                    const uint64_t n0 = !(ftp[i] || fsp[i]) ? ext_hops(i) * g.descs[i].hop : fend[i];
                     // (the tail of a fused track is cut into short items: many brief workgroups beside the fused kernel
                     // instead of one long-running one)
                     const uint32_t span = ftp[i] && kind == 0 ? kTailSpan : 0;
@@ -638,6 +646,29 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     HIPCHK(hipEventRecord(ctx->ev_join, tail_st));
     HIPCHK(hipEventRecord(ctx->ev[2], st));
+    if (!ctx->fp_ext_hops.empty()) {
+        // hr_loudnorm_first_pass: the leading hops of the 192 kHz pseudo-tracks straight from their source PCM
+        std::vector<FpItem> &fp = ctx->h_fp_items;
+        fp.clear();
+        for (size_t i = 0; i < nt && i < ctx->fp_ext_hops.size(); i++) {
+            const uint64_t eh = ext_hops(i);
+            if (!eh) continue;
+            FpSrc &src = ctx->fp_srcs[i];
+            src.rec_base = g.descs[i].rec_base;
+            src.desc = static_cast<uint32_t>(i);
+            src.rate192 = g.descs[i].rate_idx;
+            for (uint32_t c = 0; c < src.channels; c++)
+                for (uint64_t h = 0; h < eh; h += 64)
+                    fp.push_back({static_cast<uint32_t>(i), c, static_cast<uint32_t>(h), static_cast<uint32_t>(std::min<uint64_t>(64, eh - h))});
+        }
+        if (!fp.empty()) {
+            rc = upload(ctx->fp_src_d, ctx->fp_srcs.data(), ctx->fp_srcs.size() * sizeof(FpSrc), st);
+            if (!rc) rc = upload(ctx->fp_items_d, fp.data(), fp.size() * sizeof(FpItem), st);
+            if (rc) return rc;
+            launch_first_pass_rows(ctx->fp_src_d.as<FpSrc>(), dr, ctx->fp_items_d.as<FpItem>(), static_cast<uint32_t>(fp.size()),
+                                   ctx->recs.as<HopRec>(), ctx->peaks.as<unsigned long long>(), st);
+        }
+    }
     {
         const FusedItem *fi = ctx->fitems_d.as<FusedItem>();
         // HR_ABLATE (timing experiments): low 2 bits pick the kernel variant, bits 4.. are the kernel's dbg flags
@@ -1084,7 +1115,7 @@ void hr_destroy(hr_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ebu_edges, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
                       &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->comb_items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
-                      &ctx->stage, &ctx->halos})
+                      &ctx->stage, &ctx->halos, &ctx->fp_src_d, &ctx->fp_items_d})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
     delete ctx->shard_group;
@@ -1658,7 +1689,9 @@ try {
         // tracks [i, j): as many as fit the resampled-PCM budget (at least one)
         std::vector<hr_track> pseudo;
         std::vector<size_t> src_idx, off;
-        size_t need = 0, j = i;
+        struct Ext { uint64_t hops, n_start, pos_begin; };  // see below: what k_first_pass_rows takes, where the resampled rest starts
+        std::vector<Ext> ext;
+        size_t need = 0, staged = 0, j = i;
         for (; j < n; j++) {
             const hr_track &t = tracks[j];
             std::memset(&out[j], 0, sizeof out[j]);
@@ -1676,8 +1709,24 @@ try {
             if (rt->swr_phases > 0)
                 m = t.frames >= kSwrTaps + 1
                         ? (t.frames * rt->swr_phases * static_cast<uint64_t>(rt->swr_S) + rt->swr_step - 1) / rt->swr_step : 0;
-            const size_t bytes = (m * t.channels * sizeof(double) + 255) / 256 * 256;
-            if (!pseudo.empty() && need + bytes > limit) break;
+            // Whole 192 kHz hops whose input windows stay clear of the end of the track (frames up to position + 16) are
+            // measured straight from the input PCM by k_first_pass_rows: exact phase counts, an input hop that is a whole
+            // number of resampler cycles (then it yields exactly 19 200 outputs).  Only the rest -- from one input position
+            // in front of the first hop that is left, for its two samples of filter history -- is resampled into memory.
+            uint64_t eh = 0, n_start = 0, pos_begin = 0;
+            const uint64_t hop_in = t.sample_rate / 10;
+            if (ctx->cfg.engine != 1 && m && rt->swr_phases > 0 && rt->swr_S == 1 && rt->swr_step >= 1 && hop_in * 10 == t.sample_rate &&
+                hop_in % static_cast<uint64_t>(rt->swr_step) == 0 && hop_in * rt->swr_phases / rt->swr_step == 19200 &&
+                hop_in <= (1u << 20) && t.frames >= 2 * hop_in + 64) {
+                eh = std::min<uint64_t>((t.frames - 16) / hop_in, 0xffffff00u);
+                pos_begin = eh * hop_in - 1;
+                n_start = (pos_begin * rt->swr_phases + rt->swr_step - 1) / rt->swr_step;
+            }
+            const size_t bytes = ((m - n_start) * t.channels * sizeof(double) + 255) / 256 * 256;
+            // (host tracks of a group are staged side by side: their bytes count against the same budget)
+            const size_t in_stage = (t.flags & HR_TRACK_DEVICE_PCM) ? 0 : (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
+            if (!pseudo.empty() && need + staged + bytes + in_stage > limit) break;
+            staged += in_stage;
             hr_track p = t;
             p.frames = m;
             p.sample_rate = 192000;
@@ -1687,22 +1736,34 @@ try {
             pseudo.push_back(p);
             src_idx.push_back(j);
             off.push_back(need);
+            ext.push_back({eh, n_start, pos_begin});
             need += bytes;
         }
         if (!pseudo.empty()) {
             int rc = ctx->resampled.ensure(need + 256) ? HR_OK : HR_ERR_OOM;
+            // host tracks are staged side by side (k_first_pass_rows reads them while the group is measured)
+            size_t stage_need = 0;
+            std::vector<size_t> soff(pseudo.size(), 0);
+            for (size_t k = 0; k < pseudo.size(); k++) {
+                const hr_track &t = tracks[src_idx[k]];
+                if (t.flags & HR_TRACK_DEVICE_PCM) continue;
+                soff[k] = stage_need;
+                stage_need += (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
+            }
+            if (!rc && stage_need && !ctx->stage.ensure(stage_need + 256)) rc = HR_ERR_OOM;
+            ctx->fp_srcs.assign(pseudo.size(), FpSrc{});
+            ctx->fp_ext_hops.assign(pseudo.size(), 0);
             for (size_t k = 0; k < pseudo.size() && !rc; k++) {
                 const hr_track &t = tracks[src_idx[k]];
-                double *dst = reinterpret_cast<double *>(static_cast<char *>(ctx->resampled.p) + off[k]);
+                // (the pseudo-track's frame n_start sits at the start of its share of the buffer: nothing in front of it is read)
+                double *dst = reinterpret_cast<double *>(static_cast<char *>(ctx->resampled.p) + off[k]) - ext[k].n_start * t.channels;
                 pseudo[k].pcm = dst;
                 const size_t in_bytes = t.frames * t.channels * fmt_bytes(t.fmt);
                 if (!pseudo[k].frames || !in_bytes) continue;
                 const void *src = t.pcm;
                 if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
-                    if (!ctx->stage.ensure(in_bytes + 256)) { rc = HR_ERR_OOM; break; }
-                    if (hipMemcpyAsync(ctx->stage.p, t.pcm, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = HR_ERR_HIP; break; }
-                    // (a grown staging buffer is a new allocation: hipFree of the old one waits for the work that reads it)
-                    src = ctx->stage.p;
+                    src = static_cast<char *>(ctx->stage.p) + soff[k];
+                    if (hipMemcpyAsync(const_cast<void *>(src), t.pcm, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = HR_ERR_HIP; break; }
                 }
                 // always libswresample's bank, whatever interpolator the context's own tables hold
                 const RateTables *rt = rate_tables(t.sample_rate);
@@ -1719,9 +1780,21 @@ try {
                 }
                 if (rt->swr_phases > 0)
                     launch_resample_swr(t.fmt, src, t.frames, t.channels, rt->swr_phases, rt->swr_step, rt->swr_S, rt->swr_frac_scale,
-                                        rt->swr_inv_src_incr, bank, dst, st);
+                                        rt->swr_inv_src_incr, bank, dst, ext[k].pos_begin, st);
                 else  // 192 kHz input: the resampler passes it through; the f64 copy keeps one code path
-                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, 1, 1u, 1.0, ctx->unit_tap.as<double>(), dst, st);
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, 1, 1u, 1.0, ctx->unit_tap.as<double>(), dst, 0, st);
+                if (ext[k].hops) {
+                    FpSrc &fs = ctx->fp_srcs[k];
+                    fs.pcm = src;
+                    fs.frames = t.frames;
+                    fs.taps = bank;
+                    fs.channels = t.channels;
+                    fs.fmt = static_cast<uint32_t>(t.fmt);
+                    fs.hop_in = t.sample_rate / 10;
+                    fs.phases = rt->swr_phases;
+                    fs.step = rt->swr_step;
+                    ctx->fp_ext_hops[k] = ext[k].hops;
+                }
             }
             if (!rc && hipGetLastError() != hipSuccess) rc = HR_ERR_HIP;
             std::vector<hr_result> res(pseudo.size());
@@ -1730,6 +1803,8 @@ try {
                 for (size_t k = 0; k < idx.size(); k++) idx[k] = k;
                 rc = analyze_group(ctx, pseudo.data(), idx, res.data());
             }
+            ctx->fp_ext_hops.clear();
+            ctx->fp_srcs.clear();
             for (size_t k = 0; k < pseudo.size(); k++) {
                 if (rc) out[src_idx[k]].status = rc;
                 else out[src_idx[k]] = res[k];

@@ -36,8 +36,9 @@ void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkIt
 void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
 // libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases*S/step) interleaved f64 frames
 // (S, frac_scale, inv_src_incr: RateTables::swr_S / swr_frac_scale / swr_inv_src_incr; 1, 1, 1.0 for exact phase counts)
+// pos0: first input position whose outputs are written (dst still addresses output n at dst[n * channels + c])
 void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, int S, uint32_t frac_scale,
-                         double inv_src_incr, const double *taps, double *dst, hipStream_t st);
+                         double inv_src_incr, const double *taps, double *dst, uint64_t pos0, hipStream_t st);
 // tp_kind: 0 = the context's interpolation bank (libswresample's or BS.1770's, RateDev), 2 = sample peak; every item
 // covers `span` (multiple of 256) positions, or item.pad positions when that is non-zero (bank kernel only)
 void launch_true_peak_generic(int fmt, int tp_kind, const TrackDesc *tracks, const RateDev *rates,
@@ -64,6 +65,23 @@ int fused_tp_class(int tp_mt, int tp_last_rows);
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
                        HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, int variant, int tp_class, int dbg,
                        hipStream_t st);
+
+// hr_kernels_firstpass.hip: the loudnorm first pass of whole 192 kHz hops straight from the input PCM (no resampled stream)
+struct FpSrc {            // one source track
+    const void *pcm;      // device, interleaved, at the input rate
+    uint64_t frames;
+    uint64_t rec_base;    // of its 192 kHz descriptor: (hop h, ch c) is rec_base + (kPreRec + h)*channels + c
+    const double *taps;   // libswresample's bank for the input rate, [phases][32]
+    uint32_t channels, fmt;
+    uint32_t hop_in;      // input frames per 192 kHz hop (fs / 10; a multiple of `step`)
+    int32_t phases, step;
+    uint32_t desc;        // index of the 192 kHz descriptor (its peak slots)
+    int32_t rate192;      // index of the 192 kHz rate tables
+    int32_t pad_;
+};
+struct FpItem { uint32_t src, ch, first_hop, n_rows; };  // one wave: hops first_hop .. first_hop + n_rows - 1 (<= 64) of channel ch
+void launch_first_pass_rows(const FpSrc *srcs, const RateDev *rates, const FpItem *items, uint32_t n_items, HopRec *recs,
+                            unsigned long long *peaks, hipStream_t st);
 
 // hr_gain.hip: interleaved PCM of format fmt times vol (f32) -> packed s24 (dst dword aligned); *clipped += samples
 // that saturated

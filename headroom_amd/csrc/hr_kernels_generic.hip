@@ -814,10 +814,10 @@ __global__ void __launch_bounds__(256) k_true_peak_swr(const TrackDesc *__restri
 template <int FMT>
 __global__ void __launch_bounds__(256) k_resample_swr(const void *__restrict__ src, int64_t N, int C, int P, int step, int S,
                                                       uint32_t frac_scale, double inv_src_incr,
-                                                      const double *__restrict__ taps, double *__restrict__ dst)
+                                                      const double *__restrict__ taps, double *__restrict__ dst, int64_t pos0)
 {
     const int64_t stride = static_cast<int64_t>(gridDim.x) * 256;
-    for (int64_t pos = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; pos < N; pos += stride) {
+    for (int64_t pos = pos0 + static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; pos < N; pos += stride) {
         const int64_t n_lo = swr_first_output(pos * P, step, S);
         const int64_t n_hi = swr_first_output((pos + 1) * P, step, S);
         for (int c = 0; c < C; c++) {
@@ -924,10 +924,10 @@ __global__ void __launch_bounds__(256) k_resample_swr_phase(const void *__restri
 }
 
 void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels, int phases, int step, int S, uint32_t frac_scale,
-                         double inv_src_incr, const double *taps, double *dst, hipStream_t st)
+                         double inv_src_incr, const double *taps, double *dst, uint64_t pos0, hipStream_t st)
 {
-    if (!frames) return;
-    if (S == 1 && step > 1 && step <= 160 && phases >= 4) {
+    if (!frames || pos0 >= frames) return;
+    if (pos0 == 0 && S == 1 && step > 1 && step <= 160 && phases >= 4) {
         const uint64_t cycles = (frames + static_cast<uint64_t>(step) - 1) / static_cast<uint64_t>(step);
         const uint64_t n_total = (frames * static_cast<uint64_t>(phases) + static_cast<uint64_t>(step) - 1) / static_cast<uint64_t>(step);
         const uint64_t tiles = (cycles + kRsCycles - 1) / kRsCycles;
@@ -943,16 +943,17 @@ void launch_resample_swr(int fmt, const void *src, uint64_t frames, int channels
         }
     }
     // (a tile's phase numerators stay below 256 * phases + step)
-    if (S == 1 && 256ull * static_cast<uint64_t>(phases) + static_cast<uint64_t>(step) < 0x7fffffffull && (frames + 255) / 256 < 0x7fffffffull) {
+    if (pos0 == 0 && S == 1 && 256ull * static_cast<uint64_t>(phases) + static_cast<uint64_t>(step) < 0x7fffffffull && (frames + 255) / 256 < 0x7fffffffull) {
         const dim3 grid(static_cast<uint32_t>((frames + 255) / 256));
 #define HR_RT_CASE(F) case F: k_resample_swr_tiled<F><<<grid, dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, taps, dst); break;
         switch (fmt) { HR_RT_CASE(0) HR_RT_CASE(1) HR_RT_CASE(2) HR_RT_CASE(3) default: HR_RT_CASE(4) }
 #undef HR_RT_CASE
         return;
     }
-    uint64_t blocks = (frames + 255) / 256;
+    // (from input position pos0 on: dst still addresses output n at dst[n * channels + c])
+    uint64_t blocks = (frames - pos0 + 255) / 256;
     if (blocks > 256 * 64) blocks = 256 * 64;
-#define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, S, frac_scale, inv_src_incr, taps, dst); break;
+#define HR_RS_CASE(F) case F: k_resample_swr<F><<<dim3(static_cast<uint32_t>(blocks)), dim3(256), 0, st>>>(src, static_cast<int64_t>(frames), channels, phases, step, S, frac_scale, inv_src_incr, taps, dst, static_cast<int64_t>(pos0)); break;
     switch (fmt) { HR_RS_CASE(0) HR_RS_CASE(1) HR_RS_CASE(2) HR_RS_CASE(3) default: HR_RS_CASE(4) }
 #undef HR_RS_CASE
 }
