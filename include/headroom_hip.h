@@ -302,8 +302,9 @@ int hr_gain_decision_for_result(const hr_result *r, int kind, int has_bitrate, u
  * end) and then measured AT 192 kHz: K-weighting for fs = 192000, libavfilter/ebur128.c's 1000 x 0.1 LU histogram
  * gating with its channel map by index (L R C LFE Ls Rs: LFE and channels beyond six unweighted), and the sample
  * peak of the resampled signal as `input_tp`.  The context's gate / true-peak modes are not used.  Same batch
- * semantics as hr_analyze_batch.  Rates above 192 kHz: HR_ERR_RATE.  This is a parity mode (the resampled stream is
- * 4-4.35x the input, in f64, and takes the generic kernels); hr_analyze_batch is the fast path. */
+ * semantics as hr_analyze_batch.  Rates above 192 kHz: HR_ERR_RATE.  Ten times the arithmetic of hr_analyze_batch per
+ * input sample (every 192 kHz output is a 32-tap f64 dot product and a K-weighting step): about a tenth of its rate.
+ * hr_config.engine = 1 takes the older path (the whole resampled stream in device memory, generic kernels). */
 int hr_loudnorm_first_pass(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out);
 
 /* Lossless gain for PCM files, replacing `ffmpeg -i in -af volume={gain}dB -c:a pcm_s24le|pcm_s24be out`
