@@ -103,6 +103,9 @@ def main():
     ap.add_argument("--total-tracks", type=int, default=0,
                     help="config3 with --gpus N > 1 (or this flag): the whole batch is this many tracks (default 10000 = BASELINE "
                          "configs[2]) split over the ranks by bytes, strong scaling")
+    ap.add_argument("--first-pass", type=int, default=0, metavar="N",
+                    help="also time hr_loudnorm_first_pass (the literal loudnorm first pass at 192 kHz, src/analyzer.rs:261) on the first N "
+                         "tracks; reported beside, never as value")
     ap.add_argument("--host-pcm", type=int, default=0, metavar="N",
                     help="also time N tracks handed over as pinned HOST buffers (PCIe-inclusive; reported beside, never as value)")
     args = ap.parse_args()
@@ -251,6 +254,21 @@ def main():
             worst_i = max(abs(res[i]["integrated_lufs"] - ref[i]["integrated_lufs"]) for i in range(len(ref)))
             same_tp = all(res[i]["peak_per_ch"] == ref[i]["peak_per_ch"] for i in range(len(ref)))
             line["parity_check"] = {"tracks": len(ref), "max_abs_lufs_diff": worst_i, "true_peak_bit_identical": same_tp}
+        if args.first_pass > 0:
+            nf = min(args.first_pass, n_tracks)
+            fres = meter.loudnorm_first_pass(specs[:nf])
+            torch.cuda.synchronize()
+            best = None
+            for _ in range(3):
+                t1 = time.perf_counter()
+                fres = meter.loudnorm_first_pass(specs[:nf])
+                dt = time.perf_counter() - t1
+                best = dt if best is None or dt < best else best
+            assert all(r["status"] == 0 for r in fres)
+            line["first_pass"] = {"tracks": nf, "audio_hours_per_s": nf * SECONDS / 3600.0 / best, "ms_per_call": best * 1e3,
+                                  "max_abs_lufs_diff_to_default_mode": max(abs(fres[i]["integrated_lufs"] - res[i]["integrated_lufs"]) for i in range(nf)),
+                                  "true_peak_equal_to_default_mode": all(abs(fres[i]["true_peak_dbtp"] - res[i]["true_peak_dbtp"]) < 0.05 for i in range(nf)),
+                                  "note": "hr_loudnorm_first_pass: resample to 192 kHz (kept in registers), K-weighting at 192 kHz, libebur128 gating; ~10x the arithmetic of the default mode per input sample"}
         if args.host_pcm > 0:
             # the boundary also takes host buffers: same tracks from pinned host memory, H2D staging included
             nh = min(args.host_pcm, n_tracks)

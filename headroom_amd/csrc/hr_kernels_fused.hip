@@ -1545,21 +1545,21 @@ __global__ void __launch_bounds__(256) k_refine_cands(const TrackDesc *__restric
 //     same phase of the bank at every step -- and a wave 64 such runs (item.first, a multiple of `step` frames; item.pad
 //     positions count from there), one wave per channel.  The window of position p (frames p-15 .. p+16) sits in 32
 //     registers, frame f in register (f - p0 + 15) mod 32: the loop is unrolled 32 positions deep, so every index is static.
-//   * PCM arrives 16 frames per lane and load (f32 / s16, range inside the track: FAST), one load ahead; at the
+//   * PCM arrives 8 frames per lane and load (f32 / s16, range inside the track: FAST), one load ahead; at the
 //     track's edges and for packed s24 (FAST = false) frame by frame through fetch_f32s (reflection, halos, zeros).
 //   * Same FMA chain as exact_output / k_true_peak_swr / the oracle (taps 0..31 in order, from 0.0): same bits.
 // Replaces libswresample's swr_convert + f_ebur128's fabs max for those positions (reached from src/analyzer.rs:253-267).
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
 typedef unsigned u4u __attribute__((ext_vector_type(4), aligned(4)));
 
-// frames f0 .. f0+15 of channel c
+// frames f0 .. f0+7 of channel c
 template <int INF, bool FAST>
-__device__ __forceinline__ void tp_rows_chunk(const TrackDesc &t, int c, int64_t f0, float (&dst)[16])
+__device__ __forceinline__ void tp_rows_chunk(const TrackDesc &t, int c, int64_t f0, float (&dst)[8])
 {
     if constexpr (FAST && INF == 0) {
         const f4u *p = reinterpret_cast<const f4u *>(static_cast<const char *>(t.pcm) + f0 * 8);
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 4; q++) {
             const f4u v = p[q];
             dst[2 * q] = c ? v[1] : v[0];
             dst[2 * q + 1] = c ? v[3] : v[2];
@@ -1568,7 +1568,7 @@ __device__ __forceinline__ void tp_rows_chunk(const TrackDesc &t, int c, int64_t
         constexpr float sc = 1.0f / 32768.0f;
         const u4u *p = reinterpret_cast<const u4u *>(static_cast<const char *>(t.pcm) + f0 * 4);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
+        for (int q = 0; q < 2; q++) {
             const u4u v = p[q];
 #pragma unroll
             for (int e = 0; e < 4; e++)  // (one dword per frame: left in the low half)
@@ -1577,7 +1577,7 @@ __device__ __forceinline__ void tp_rows_chunk(const TrackDesc &t, int c, int64_t
     } else {
         // (every sample of these formats, and of a neighbour shard's halo, is an f32 value: nothing is rounded here)
 #pragma unroll
-        for (int e = 0; e < 16; e++) dst[e] = static_cast<float>(fetch_f32s(t, c, f0 + e));
+        for (int e = 0; e < 8; e++) dst[e] = static_cast<float>(fetch_f32s(t, c, f0 + e));
     }
 }
 
@@ -1586,26 +1586,28 @@ __device__ __forceinline__ double tp_rows_body(const TrackDesc &t, int c, cdoubl
                                                int lane_lim)
 {
     double w[32], m = 0.0;
-    float ca[16], cb[16];
-    tp_rows_chunk<INF, FAST>(t, c, p0 - 16, ca);
-    tp_rows_chunk<INF, FAST>(t, c, p0, cb);
+    float ca[8], cb[8];
+    // the window of position p0: frames p0-15 .. p0+15 (slot j holds frame p0 - 15 + j; slot 31 is filled by position 0)
 #pragma unroll
-    for (int j = 0; j < 15; j++) w[j] = static_cast<double>(ca[j + 1]);
+    for (int q = 0; q < 4; q++) {
+        tp_rows_chunk<INF, FAST>(t, c, p0 - 16 + 8 * q, ca);
 #pragma unroll
-    for (int j = 15; j < 31; j++) w[j] = static_cast<double>(cb[j - 15]);
-    w[31] = 0.0;
-    tp_rows_chunk<INF, FAST>(t, c, p0 + 16, ca);  // frames p0+16 .. p0+31: what positions 0 .. 15 bring into the window
+        for (int e = 0; e < 8; e++)
+            if (8 * q + e >= 1) w[8 * q + e - 1] = static_cast<double>(ca[e]);
+    }
+    tp_rows_chunk<INF, FAST>(t, c, p0 + 16, ca);  // frames p0+16 .. p0+23: what positions 0 .. 7 bring into the window
     int d = 0;                                    // phase units of the next output beyond the current position (wave-uniform)
     for (int b = 0; b < K; b += 32) {
-        tp_rows_chunk<INF, FAST>(t, c, p0 + b + 32, cb);  // for positions b+16 .. b+31
         // position b + u; false once the lane's run is over (wave-uniform).  u is a compile-time constant, so every
         // window index below is one too.
         auto position = [&](auto uc) {
             constexpr int u = decltype(uc)::value;
             const int i = b + u;
             if (i >= K) return false;
-            if constexpr (u == 16) tp_rows_chunk<INF, FAST>(t, c, p0 + b + 48, ca);  // for positions b+32 .. b+47
-            w[(u + 31) & 31] = static_cast<double>(u < 16 ? ca[u & 15] : cb[u & 15]);  // frame p0 + i + 16
+            // (one chunk of 8 frames ahead of its use: A serves u mod 16 = 0..7, B serves 8..15)
+            if constexpr ((u & 15) == 0) tp_rows_chunk<INF, FAST>(t, c, p0 + i + 24, cb);
+            if constexpr ((u & 15) == 8) tp_rows_chunk<INF, FAST>(t, c, p0 + i + 24, ca);
+            w[(u + 31) & 31] = static_cast<double>((u & 8) ? cb[u & 7] : ca[u & 7]);  // frame p0 + i + 16
             double mp = 0.0;
             while (d < P) {  // the outputs that sit at this position: phase d of the bank
                 const cdouble_p f = taps + static_cast<size_t>(d) * kSwrTaps;
@@ -1631,10 +1633,10 @@ __device__ __forceinline__ double tp_rows_body(const TrackDesc &t, int c, cdoubl
     return m;
 }
 
-// one wave per (item, channel): blockIdx.x = 2 * item + channel; four waves per SIMD hide the scalar tap loads and the
+// one wave per (item, channel): blockIdx.x = 2 * item + channel; several waves per SIMD hide the scalar tap loads and the
 // FMA chain's latency
 template <int INF>
-__global__ void __launch_bounds__(64, 16) k_true_peak_rows(const TrackDesc *__restrict__ tracks, const RateDev *__restrict__ rates,
+__global__ void __launch_bounds__(64) k_true_peak_rows(const TrackDesc *__restrict__ tracks, const RateDev *__restrict__ rates,
                                                            const WorkItem *__restrict__ items, unsigned long long *__restrict__ peaks)
 {
     const WorkItem it = items[blockIdx.x >> 1];
