@@ -1753,6 +1753,11 @@ try {
             if (!rc && stage_need && !ctx->stage.ensure(stage_need + 256)) rc = HR_ERR_OOM;
             ctx->fp_srcs.assign(pseudo.size(), FpSrc{});
             ctx->fp_ext_hops.assign(pseudo.size(), 0);
+            // The resampled stream is read only by the generic kernels, which run_measure puts on the side stream: it is
+            // written there too, in front of them, and so beside k_first_pass_rows instead of in front of it.  (The side
+            // stream first waits for whatever the main stream still does with the buffers: the previous group's kernels.)
+            hipStream_t rs = ctx->serial_tail ? st : ctx->side;
+            if (!rc && rs != st && (hipEventRecord(ctx->ev_fork, st) != hipSuccess || hipStreamWaitEvent(rs, ctx->ev_fork, 0) != hipSuccess)) rc = HR_ERR_HIP;
             for (size_t k = 0; k < pseudo.size() && !rc; k++) {
                 const hr_track &t = tracks[src_idx[k]];
                 // (the pseudo-track's frame n_start sits at the start of its share of the buffer: nothing in front of it is read)
@@ -1764,6 +1769,7 @@ try {
                 if (!(t.flags & HR_TRACK_DEVICE_PCM)) {
                     src = static_cast<char *>(ctx->stage.p) + soff[k];
                     if (hipMemcpyAsync(const_cast<void *>(src), t.pcm, in_bytes, hipMemcpyHostToDevice, st) != hipSuccess) { rc = HR_ERR_HIP; break; }
+                    if (rs != st && (hipEventRecord(ctx->ev_fork, st) != hipSuccess || hipStreamWaitEvent(rs, ctx->ev_fork, 0) != hipSuccess)) { rc = HR_ERR_HIP; break; }
                 }
                 // always libswresample's bank, whatever interpolator the context's own tables hold
                 const RateTables *rt = rate_tables(t.sample_rate);
@@ -1780,9 +1786,9 @@ try {
                 }
                 if (rt->swr_phases > 0)
                     launch_resample_swr(t.fmt, src, t.frames, t.channels, rt->swr_phases, rt->swr_step, rt->swr_S, rt->swr_frac_scale,
-                                        rt->swr_inv_src_incr, bank, dst, ext[k].pos_begin, st);
+                                        rt->swr_inv_src_incr, bank, dst, ext[k].pos_begin, rs);
                 else  // 192 kHz input: the resampler passes it through; the f64 copy keeps one code path
-                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, 1, 1u, 1.0, ctx->unit_tap.as<double>(), dst, 0, st);
+                    launch_resample_swr(t.fmt, src, t.frames, t.channels, 1, 1, 1, 1u, 1.0, ctx->unit_tap.as<double>(), dst, 0, rs);
                 if (ext[k].hops) {
                     FpSrc &fs = ctx->fp_srcs[k];
                     fs.pcm = src;
