@@ -1146,7 +1146,10 @@ try {
     const double ninf = -std::numeric_limits<double>::infinity();
     std::vector<size_t> cur;
     size_t cur_bytes = 0, cur_widened = 0;
-    const size_t widen_limit = 16 * ctx->cfg.stage_bytes;  // f32 copies of integer tracks (16 GiB by default)
+    // stereo planes of split tracks per group: 16 GiB by default, and up to a third of the device memory that is free (at
+    // most 96 GiB) -- a launch that fills several rounds of the GPU's wave slots wastes less on its last, partial round
+    size_t widen_limit = 16 * ctx->cfg.stage_bytes;
+    bool widen_probed = false;
     int fatal = HR_OK;
     auto flush = [&]() {
         cur_widened = 0;
@@ -1170,6 +1173,13 @@ try {
         const size_t bytes = on_device(ctx, tracks[i])
                                  ? 0 : tracks[i].frames * tracks[i].channels * fmt_bytes(tracks[i].fmt) + 256;
         const size_t wbytes = splits(ctx, tracks[i]) ? split_bytes(tracks[i]) : 0;
+        if (wbytes && !widen_probed) {
+            widen_probed = true;
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+                widen_limit = std::max(widen_limit, std::min<size_t>(96ull << 30, (free_b + ctx->widened.cap) / 3));
+            else (void)hipGetLastError();
+        }
         if (!cur.empty() && (cur_bytes + bytes > ctx->cfg.stage_bytes || cur_widened + wbytes > widen_limit)) flush();
         cur.push_back(i);
         cur_bytes += bytes;
@@ -1672,7 +1682,13 @@ try {
     static const float wln[HR_MAX_CH + 1][HR_MAX_CH] = {
         {0}, {1}, {1, 1}, {1, 1, 1}, {1, 1, 1.41f, 1.41f}, {1, 1, 1, 1.41f, 1.41f},
         {1, 1, 1, 0, 1.41f, 1.41f}, {1, 1, 1, 0, 1.41f, 1.41f, 0}, {1, 1, 1, 0, 1.41f, 1.41f, 0, 0}};
-    const hr_config saved = ctx->cfg;
+    // (restored, and the first-pass hand-over to run_measure withdrawn, however this function is left: an exception on
+    // the way must not leave the context in loudnorm's modes)
+    struct Restore {
+        hr_ctx *c;
+        hr_config saved;
+        ~Restore() { c->cfg = saved; c->fp_ext_hops.clear(); c->fp_srcs.clear(); }
+    } restore{ctx, ctx->cfg};
     ctx->cfg.gate_mode = HR_GATE_LOUDNORM;
     ctx->cfg.tp_mode = HR_TP_SAMPLE;
     const double ninf = -std::numeric_limits<double>::infinity(), nan = std::numeric_limits<double>::quiet_NaN();
@@ -1819,7 +1835,6 @@ try {
         }
         i = j;
     }
-    ctx->cfg = saved;
     return fatal;
 } HR_CATCH_ALL
 
