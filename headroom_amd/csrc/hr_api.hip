@@ -1727,7 +1727,7 @@ try {
                         ? (t.frames * rt->swr_phases * static_cast<uint64_t>(rt->swr_S) + rt->swr_step - 1) / rt->swr_step : 0;
             // Whole 192 kHz hops whose input windows stay clear of the end of the track (frames up to position + 16) are
             // measured straight from the input PCM by k_first_pass_rows: exact phase counts, an input hop that is a whole
-            // number of resampler cycles (then it yields exactly 19 200 outputs).  Only the rest -- from one input position
+            // number of resampler cycles (then it yields exactly 19 200 outputs).  Only the rest -- from three input positions
             // in front of the first hop that is left, for its two samples of filter history -- is resampled into memory.
             uint64_t eh = 0, n_start = 0, pos_begin = 0;
             const uint64_t hop_in = t.sample_rate / 10;
@@ -1735,7 +1735,9 @@ try {
                 hop_in % static_cast<uint64_t>(rt->swr_step) == 0 && hop_in * rt->swr_phases / rt->swr_step == 19200 &&
                 hop_in <= (1u << 20) && t.frames >= 2 * hop_in + 64) {
                 eh = std::min<uint64_t>((t.frames - 16) / hop_in, 0xffffff00u);
-                pos_begin = eh * hop_in - 1;
+                // (every input position holds at least one output -- the rate is at most 192 kHz -- so three positions in
+                // front of the hop hold the two outputs its filter history needs, whatever the ratio)
+                pos_begin = eh * hop_in - 3;
                 n_start = (pos_begin * rt->swr_phases + rt->swr_step - 1) / rt->swr_step;
             }
             const size_t bytes = ((m - n_start) * t.channels * sizeof(double) + 255) / 256 * 256;

@@ -41,7 +41,7 @@ def check(oracle, both, cases):
             assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6, (fs, g, ref)
 
 
-@pytest.mark.parametrize("fs", [44100, 48000, 88200, 96000, 32000, 8000])
+@pytest.mark.parametrize("fs", [44100, 48000, 88200, 96000, 176400, 128000, 32000, 8000])  # (176.4 / 128 kHz: fewer than two outputs per input position)
 def test_rates(oracle, both, fs):
     secs = 7.7 if fs <= 48000 else 3.3   # more than one wave of 64 hops at the common rates
     x = signals.seeded_noise(500 + fs, int(fs * secs) + 29, 2, -14.0)
