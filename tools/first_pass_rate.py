@@ -1,13 +1,16 @@
-"""How fast is the literal loudnorm first pass (resample to 192 kHz f64, measure there)?"""
+"""How fast is the literal loudnorm first pass (resample to 192 kHz f64, measure there)?
+python tools/first_pass_rate.py TRACKS SECONDS [RATE [ENGINE]]   (engine 1: the all-in-memory path)"""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import headroom_amd as hr
-n, secs, fs = int(sys.argv[1]), float(sys.argv[2]), 44100
+n, secs = int(sys.argv[1]), float(sys.argv[2])
+fs = int(sys.argv[3]) if len(sys.argv) > 3 else 44100
+engine = int(sys.argv[4]) if len(sys.argv) > 4 else 0
 frames = int(fs * secs)
 dev = torch.device("cuda:0")
 pcm = torch.empty((n, frames, 2), dtype=torch.float32, device=dev)
-m = hr.Meter(device=0)
+m = hr.Meter(device=0, engine=engine)
 for i in range(n):
     m.synth_fill(pcm[i].data_ptr(), 1000 + i, fs, 2, frames)
 torch.cuda.synchronize()
