@@ -361,9 +361,18 @@ const RateTables *rate_tables(uint32_t fs)
     static std::mutex mu;
     static std::map<uint32_t, std::unique_ptr<RateTables>> cache;
     if (fs < 10) return nullptr;
+    // (a batch asks for the same rate several times per track: the last answer of this thread needs no lock; tables are
+    // never freed)
+    static thread_local uint32_t last_fs = 0;
+    static thread_local const RateTables *last = nullptr;
+    if (last && last_fs == fs) return last;
     std::lock_guard<std::mutex> lk(mu);
     auto it = cache.find(fs);
-    if (it != cache.end()) return it->second.get();
+    if (it != cache.end()) {
+        last_fs = fs;
+        last = it->second.get();
+        return last;
+    }
     auto rt = std::make_unique<RateTables>();
     rt->fs = fs;
     rt->hop = fs / 10;
