@@ -80,3 +80,26 @@ def test_device_pcm_and_low_frequency_content(oracle, both):
         g = m.loudnorm_first_pass([hr.TrackSpec(dev, fs)])[0]
         assert g["peak_per_ch"] == ref["peak_per_ch"]
         assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+
+
+def test_committed_first_pass_vectors(both):
+    """tests/golden/first_pass_vectors.json (generated from the oracle by make_golden_first_pass.py, no reference on the
+    GPU box): same generator on the device (hr_synth_fill), both paths of hr_loudnorm_first_pass."""
+    import json
+    import os
+    import torch
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "first_pass_vectors.json")) as fh:
+        cases = json.load(fh)["cases"]
+    for m in both:
+        bufs, specs = [], []
+        for c in cases:
+            t = torch.empty((c["frames"], c["channels"]), dtype=torch.float32, device="cuda:0")
+            m.synth_fill(t.data_ptr(), c["seed"], c["fs"], c["channels"], c["frames"])
+            bufs.append(t)
+            specs.append(hr.TrackSpec(t, c["fs"]))
+        torch.cuda.synchronize()
+        for c, g in zip(cases, m.loudnorm_first_pass(specs)):
+            assert g["status"] == 0 and g["n_blocks"] == c["n_blocks"] and g["n_gated"] == c["n_gated"], (c["seed"], g)
+            assert [float.hex(float(x)) for x in g["peak_per_ch"][: c["channels"]]] == c["peak_per_ch"], (c["seed"], g)
+            want = float.fromhex(c["integrated_lufs"])
+            assert g["integrated_lufs"] == want or abs(g["integrated_lufs"] - want) < 1e-6, (c["seed"], g, want)

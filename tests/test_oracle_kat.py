@@ -372,3 +372,23 @@ def test_apply_gain_known_answers(oracle):
     # saturation: +1.0 full scale cannot be represented, -1.0 can
     out, clipped = oracle.apply_gain(np.array([[1.0, -1.0]], dtype=np.float32), 48000, 0.0)
     assert clipped == 1 and bytes(out) == b"\xff\xff\x7f\x00\x00\x80"
+
+
+# ---- committed first-pass vectors (tests/golden/make_golden_first_pass.py) --------------------------------------
+
+def _golden_first_pass():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "first_pass_vectors.json")) as fh:
+        return json.load(fh)["cases"]
+
+
+@pytest.mark.parametrize("idx", range(9))
+def test_oracle_reproduces_first_pass_vectors(oracle, idx):
+    c = _golden_first_pass()[idx]
+    r = oracle.loudnorm_measure(oracle.synth_track(c["seed"], c["fs"], c["channels"], c["frames"]), c["fs"])
+    assert r["n_blocks"] == c["n_blocks"] and r["n_gated"] == c["n_gated"]
+    assert [float.hex(float(x)) for x in r["peak_per_ch"]] == c["peak_per_ch"]
+    for k in ("integrated_lufs", "rel_threshold_lufs", "true_peak_dbtp"):
+        want = float.fromhex(c[k])
+        assert r[k] == want or abs(r[k] - want) < 1e-10, (k, r[k], want)
