@@ -72,6 +72,14 @@ constexpr size_t kMaxRatesPerCtx = 64;  // device tables are kept per distinct r
 constexpr uint32_t kPeakSpan = 8192;  // positions per workgroup of the generic true-peak kernels
 constexpr uint32_t kTailSpan = 512;   // ... for the tail of a track whose body runs on the fused kernel
 
+// frames of a track (frame bytes fb) after which a 16-byte chunk grid repeats: 16 / gcd(16, fb)
+uint64_t chunk_frames(uint32_t fb)
+{
+    uint32_t g = 16;
+    while (fb % g) g /= 2;
+    return 16 / g;
+}
+
 size_t fmt_bytes(int fmt)
 {
     switch (fmt) {
@@ -107,6 +115,11 @@ struct hr_ctx {
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
     std::vector<WorkItem> h_items, h_comb_items;
     std::vector<FusedItem> h_fitems;
+    // the fused launches of the last run_measure, per kernel class: items [item_off, item_off + n_items) of h_fitems, their
+    // candidate lists [list_off, list_off + n_items * wpi) (wpi lists per item: 1, or channels / 2 for a multichannel track
+    // read directly, list w of an item being channels 2 w and 2 w + 1)
+    struct FusedRun { size_t item_off, n_items, list_off; uint32_t wpi; };
+    std::vector<FusedRun> h_runs;
     std::vector<uint8_t> h_ftp;       // per track of the last run_measure: its true peak went through the fused kernel
     std::vector<uint64_t> h_fend;     // ... which screened the positions in front of this one (redo_overflowed_peaks)
     std::vector<unsigned> h_ovf, h_cand_cnt;  // redo_overflowed_peaks: the flags of the last launch, read back
@@ -149,7 +162,7 @@ struct hr_ctx {
 // ---- workspace of hr_analyze_device_noalloc: one array per GPU that the library runs on, held until the process ends ----
 // Host code never uses the array's name as an address: hr_init asks the runtime for the array's address on the current
 // device (hipGetSymbolAddress) and keeps it per device; kernels, memsets and copies take that pointer.
-constexpr size_t kScratchBytes = 8u << 20;
+constexpr size_t kScratchBytes = 16u << 20;
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
 constexpr int kMaxDevices = 64;
 static void *g_scratch_ptr[kMaxDevices];      // per device; filled once by hr_init under g_scratch_init_mu
@@ -254,6 +267,8 @@ int validate_track(const hr_ctx *ctx, const hr_track &t)
     return HR_OK;
 }
 
+bool fused_mc(const hr_ctx *ctx, const hr_track &t, const void *dev);  // (below, beside the other routing predicates)
+
 // One launch group: descriptors already built in `descs` (host), PCM resident on the device.
 struct Group {
     std::vector<TrackDesc> descs;
@@ -316,14 +331,22 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     // hops; its true-peak half additionally needs HR_TP_SWR192K and the rate's f16 tile table.  The fused
     // kernel covers hops 0 .. n_hops-2; the last hop and the ragged tail stay on the generic kernels.
     std::vector<uint8_t> fkw(nt, 0), ftp(nt, 0), fsp(nt, 0);  // fused K-weighting / + true-peak screen / + sample peak
+    std::vector<uint8_t> fmc(nt, 0);  // ... as a 5.1 / 7.1 track read directly (fused_mc): waves per item = channels / 2
     for (size_t i = 0; i < nt; i++) {
         const TrackDesc &d = g.descs[i];
         bool ok = d.role != 1 && ctx->cfg.engine != 1 && (d.fmt == HR_FMT_F32 || d.fmt == HR_FMT_S16 || (d.fmt == HR_FMT_S24 && d.hop % 2 == 0)) && d.ch == 2 && d.n_hops >= 2 &&
                   d.hop >= 64 && (reinterpret_cast<uintptr_t>(d.pcm) & 15) == 0 && d.hop * 8ull * 64 < 0xffffffffull;
+        if (d.role == 0 && d.ch > 2 && do_peaks) {
+            hr_track as_track{};
+            as_track.frames = d.frames; as_track.sample_rate = d.fs; as_track.channels = d.ch; as_track.fmt = d.fmt;
+            ok = fused_mc(ctx, as_track, d.pcm);
+            fmc[i] = ok;
+        }
         const bool tp_ok = do_peaks && (ctx->cfg.tp_mode == HR_TP_SWR192K || ctx->cfg.tp_mode == HR_TP_BS1770) &&
                            ctx->rates_h[d.rate_idx].tp_atab != nullptr;
         // stereo s16 is read as it is by the full pass only (K-weighting + true-peak screen); see fused_s16()
         if (d.fmt != HR_FMT_F32 && (!tp_ok || ctx->no_s16_direct)) ok = false;
+        if (fmc[i] && !tp_ok) ok = false, fmc[i] = 0;
         fkw[i] = ok;
         ftp[i] = ok && tp_ok;
         // the peak is the plain sample peak: HR_TP_SAMPLE, 192 kHz input (nothing to interpolate)
@@ -353,9 +376,9 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     for (size_t i = 0; i < nt; i++) sub_from[i] = g.descs[i].n_hops;
     {
         auto final_row_ok = [&](const TrackDesc &d, uint64_t len) {  // (see ffin below)
-            const uint32_t fb = fmt_bytes(d.fmt) * 2;
-            const uint64_t align = fb == 8 ? 2 : fb == 4 ? 4 : 8, T = (len + 15) / 16;
-            return d.stream_end && !d.right_head && (d.frames - (d.n_hops * d.hop - len) >= 16 * (T + 1) || d.frames % align == 0);
+            const uint32_t fb = fmt_bytes(d.fmt) * d.ch;
+            const uint64_t T = (len + 15) / 16, row0 = d.n_hops * d.hop - len;
+            return d.stream_end && !d.right_head && (d.frames - row0 >= 16 * (T + 1) || (d.frames - row0) % chunk_frames(fb) == 0);
         };
         // waves and wave-steps of a track as whole hops (0), as shorter rows throughout (1), and with only the hops that
         // do not fill a wave of whole-hop rows as shorter rows (2: those waves run a third of the steps)
@@ -372,7 +395,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             const uint64_t P = static_cast<uint64_t>(rd.sub_parts);
             const uint64_t len = P > 1 ? d.hop / P : d.hop;
             c.can = P > 1 && !d.left_tail && !d.right_head && d.blk_first == 0 && d.stream_start &&
-                    (len * fmt_bytes(d.fmt) * 2) % 16 == 0 && final_row_ok(d, len);
+                    (len * fmt_bytes(d.fmt) * d.ch) % 16 == 0 && final_row_ok(d, len);
             for (int k = 1; k < 3; k++) { c.waves[k] = c.waves[0]; c.steps[k] = c.steps[0]; }
             if (!c.can) continue;
             const uint64_t tP = (len + 15) / 16 + 1;
@@ -385,6 +408,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                 c.steps[2] = full * t1 + wl * tP;
             }
         }
+        // (an item of a multichannel track read directly is channels / 2 waves)
+        auto wpi_of = [&](size_t i) { return fmc[i] ? static_cast<uint64_t>(g.descs[i].ch / 2) : uint64_t{1}; };
         // the track's own best: fuller waves must pay for the fixed cost of more rows (3 %); shorter LAST waves cost nothing
         auto own_choice = [&](size_t i) {
             const Cost &c = cost[i];
@@ -401,8 +426,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             for (size_t i = 0; i < nt; i++) {
                 if (!cost[i].waves[0]) continue;
                 const int k = choice(i);
-                waves += static_cast<double>(cost[i].waves[k]);
-                steps += static_cast<double>(cost[i].steps[k]);
+                waves += static_cast<double>(cost[i].waves[k] * wpi_of(i));
+                steps += static_cast<double>(cost[i].steps[k] * wpi_of(i));
             }
             if (waves == 0) return 0.0;
             const double rounds = waves / 2048.0, whole = std::floor(rounds), frac = rounds - whole;
@@ -412,7 +437,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         auto all_sub = [&](size_t i) { return cost[i].can ? 1 : 0; };
         const double est_b = estimate(own_choice), est_c = estimate(all_sub);
         double waves_a = 0;
-        for (size_t i = 0; i < nt; i++) waves_a += static_cast<double>(cost[i].waves[0]);
+        for (size_t i = 0; i < nt; i++) waves_a += static_cast<double>(cost[i].waves[0] * wpi_of(i));
         // (measured: over several rounds shorter rows everywhere gain nothing -- 1000 three-minute tracks 19.8 against
         // 19.65 ms, and their combine kernel costs 0.4 ms more -- so that is for launches of at most one round)
         const bool everywhere = ctx->cfg.engine == 3 || (waves_a <= 2048.0 && est_c < 0.985 * est_b);
@@ -429,17 +454,17 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         // Whole rounds of whole-hop waves: the waves beyond the last full round of the 2048 slots would run as a partial
         // round of long waves; their hops become shorter rows instead (64 hops = one wave less per step of this loop),
         // which fill the last rounds in finer grain (measured: 300 tracks 6.88 -> 6.32 ms, 500 and 1000 tracks -0.7 %).
-        if (!everywhere && ctx->cfg.engine == 0) {
+        if (!everywhere && (ctx->cfg.engine == 0 || ctx->cfg.engine == 5)) {
             uint64_t whole = 0;
             for (size_t i = 0; i < nt; i++)
-                if (cost[i].waves[0]) whole += (sub_from[i] + 63) / 64;
+                if (cost[i].waves[0]) whole += (sub_from[i] + 63) / 64 * wpi_of(i);
             uint64_t excess = whole > 2048 ? whole % 2048 : 0;
             for (int pass = 0; pass < 64 && excess; pass++)
                 for (size_t i = 0; i < nt && excess; i++) {
                     if (!cost[i].can || sub_from[i] < 64 || sub_from[i] % 64) continue;
                     sub_p[i] = static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].sub_parts);
                     sub_from[i] -= 64;
-                    excess--;
+                    excess -= std::min(excess, wpi_of(i));
                 }
         }
     }
@@ -462,17 +487,27 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         const uint64_t len = sub_from[i] < d.n_hops ? d.row_len : d.hop;  // rows of the track's last section
         const uint64_t last_hop0 = d.n_hops * d.hop - len;  // (start of the last row that belongs to a hop)
         fend[i] = last_hop0;
-        if (!d.stream_end || d.right_head || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
+        // The same care serves a time shard that has a right neighbour (round 3): its last hop ends with the shard's buffer,
+        // the frames behind it live in the halo.  The row K-weights the whole hop and screens the tiles whose windows stay
+        // inside the shard; the generic kernel, which reads the halo, takes the rest from fend on.  (Before, that hop went
+        // to the one-lane-per-channel kernel: 0.5 - 1 ms of latency beside a fused kernel of 0.5 ms per eighth of a stream.)
+        const bool track_end = d.stream_end && !d.right_head, shard_mid = !d.stream_end && d.right_head != nullptr;
+        if (!(track_end || shard_mid) || ctx->split) continue;  // (the experiments' split-wave kernel has no final-row care)
         const uint64_t ragged = d.frames - d.n_hops * d.hop;
-        const uint32_t fb = fmt_bytes(d.fmt) * 2;
+        const uint32_t fb = fmt_bytes(d.fmt) * d.ch;
         const uint64_t T = (len + 15) / 16;
-        const uint64_t align = fb == 8 ? 2 : fb == 4 ? 4 : 8;  // frames per 16 bytes of f32 / s16 / s24 stereo (s24: of 48)
+        // The DMA moves 16-byte chunks counted from the ROW's first byte (rows need not start on a 16-byte boundary of the
+        // track's image: 44.1 kHz s16 / s24, odd hop lengths), and a chunk is fetched when it starts inside the track.  So a row
+        // that reaches the end of the track must see that end on its own chunk grid: a whole number of `cf` frames from its start.
+        const uint64_t cf = chunk_frames(fb);
         // (a row fetches pieces 0 .. T: 16 (T + 1) frames from its start)
-        ffin[i] = d.frames - last_hop0 >= 16 * (T + 1) || d.frames % align == 0;
+        ffin[i] = d.frames - last_hop0 >= 16 * (T + 1) || (d.frames - last_hop0) % cf == 0;
         if (!ffin[i]) continue;
         // rows behind the last hop: the tail's whole rows (only when a row is less than a hop) and, if what is left is
-        // worth a lane, one partial row; all of them for their peak only
-        const uint64_t usable = d.frames / align * align - d.n_hops * d.hop;  // (only meaningful when ragged >= align)
+        // worth a lane, one partial row; all of them for their peak only.  They start at n_hops * hop + j * len: one row
+        // (len == hop), or rows whose length is a whole number of chunks (run_measure's `can`), so every one of them sees
+        // the same chunk grid and `usable` ends on it.
+        const uint64_t usable = (d.frames - d.n_hops * d.hop) / cf * cf;
         uint64_t tail_rows = 0;
         if (ftp[i] && ragged >= 64 && usable >= 48) {
             tail_rows = usable / len;
@@ -499,9 +534,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
-    // class 6 = K-weight only, class 7 = K-weight + sample peak, classes 8..13 / 14..19 = classes 0..5 reading stereo s16 / s24
-    constexpr int kFusedClasses = 20;
+    // class 6 = K-weight only, class 7 = K-weight + sample peak, classes 8..13 / 14..19 = classes 0..5 reading stereo s16 / s24,
+    // classes 20 + 6 (3 [7.1 instead of 5.1] + sample format) + (0..5) = a 5.1 / 7.1 track read directly (fused_mc)
+    constexpr int kStereoClasses = 20, kFusedClasses = kStereoClasses + 36;
     size_t class_off[kFusedClasses + 1];
+    auto class_wpi = [&](int cls) -> uint32_t { return cls < kStereoClasses ? 1u : ((cls - kStereoClasses) / 18 ? 4u : 3u); };
     // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
     // mixes rates or row lengths: every (class, rate, row length) run is padded to a multiple of 4 with n_rows == 0
     // copies of its last item.
@@ -512,7 +549,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     for (size_t i = 0; i < nt; i++) {
         if (!fkw[i]) continue;
         const RateDev &rd = ctx->rates_h[g.descs[i].rate_idx];
-        const int mine = ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
+        const int mine = fmc[i] ? kStereoClasses + 6 * ((g.descs[i].ch == 8 ? 3 : 0) + g.fmts[i]) + fused_tp_class(rd.tp_mt, rd.tp_last_rows)
+                       : ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
         by_class_rate[static_cast<size_t>(mine) * n_rates + g.descs[i].rate_idx].push_back(static_cast<uint32_t>(i));
     }
     for (int cls = 0; cls < kFusedClasses; cls++) {
@@ -547,7 +585,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     fitems.push_back(it);
                 }
             }
-            if (fitems.size() > run_begin) {
+            if (fitems.size() > run_begin && cls < kStereoClasses) {  // (a multichannel item is a workgroup of its own: nothing to pad)
                 FusedItem pad = fitems.back();
                 pad.last = pad.last && pad.n_rows == 1;  // (a padding wave works on row 0 of the wave it copies)
                 pad.n_rows = 0;
@@ -561,10 +599,18 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         if (rc) return rc;
     }
 
+    // candidate lists: one per wave of the launch
+    ctx->h_runs.clear();
+    size_t n_lists = 0;
+    for (int cls = 0; cls < kFusedClasses; cls++) {
+        const size_t n = class_off[cls + 1] - class_off[cls];
+        ctx->h_runs.push_back({class_off[cls], n, n_lists, class_wpi(cls)});
+        n_lists += n * class_wpi(cls);
+    }
     FusedScratch fs{};
     if (!fitems.empty()) {
-        if (!ctx->cands.ensure(fused_cand_bytes(static_cast<uint32_t>(fitems.size()))) ||
-            !ctx->cand_cnt.ensure(fitems.size() * sizeof(unsigned)) || !ctx->tpb.ensure(nt * kMaxCh * 2 * sizeof(unsigned)) ||
+        if (!ctx->cands.ensure(fused_cand_bytes(static_cast<uint32_t>(n_lists))) ||
+            !ctx->cand_cnt.ensure(n_lists * sizeof(unsigned)) || !ctx->tpb.ensure(nt * kMaxCh * 2 * sizeof(unsigned)) ||
             !ctx->overflow.ensure(nt * sizeof(unsigned)))
             return HR_ERR_OOM;
         fs.cands = ctx->cands.p;
@@ -683,8 +729,14 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             const size_t off = class_off[cls], n = class_off[cls + 1] - off;
             if (!n) continue;
             FusedScratch fsc = fs;
-            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(off));
-            fsc.cand_cnt = fs.cand_cnt + off;
+            fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(ctx->h_runs[cls].list_off));
+            fsc.cand_cnt = fs.cand_cnt + ctx->h_runs[cls].list_off;
+            if (cls >= kStereoClasses) {
+                const int sub = cls - kStereoClasses;
+                launch_fused_mc(sub / 18 ? 8 : 6, (sub / 6) % 3, sub % 6, dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
+                                ctx->peaks.as<unsigned long long>(), st);
+                continue;
+            }
             const bool tp = cls < 6;
             launch_fused_f32s(dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
                               ctx->peaks.as<unsigned long long>(),
@@ -733,7 +785,7 @@ int run_gating(hr_ctx *ctx, Group &g, bool finalize, bool range_parts = false)
         !ctx->gate_parts.ensure(static_cast<size_t>(g.part_slots) * sizeof(GatePart)) ||
         ((finalize || range_parts) && !ctx->st_hist.ensure(hist_bytes)))
         return HR_ERR_OOM;
-    // one workgroup per chunk of kGateChunk blocks: a 3-minute track is one chunk, a 10-hour stream 22
+    // one workgroup per chunk of kGateChunk blocks: a 3-minute track is one chunk, a 10-hour stream 176
     std::vector<WorkItem> &items = ctx->h_gate_items;  // (outlives the asynchronous copy)
     items.clear();
     for (uint32_t i = 0; i < nt; i++)
@@ -843,29 +895,35 @@ int overflow_redo(hr_ctx *ctx, Group &g, bool *relaunched)
     for (unsigned o : ovf) { any |= o != 0; waves |= (o & 2u) != 0; }
     if (!any) return HR_OK;
     if (waves && !ctx->h_fitems.empty()) {  // which waves: their candidate counts carry kCandOverflowBit
-        cnt.resize(ctx->h_fitems.size());
+        size_t n_lists = 0;
+        for (const auto &run : ctx->h_runs) n_lists = std::max(n_lists, run.list_off + run.n_items * run.wpi);
+        cnt.resize(n_lists);
         HIPCHK(hipMemcpyAsync(cnt.data(), ctx->cand_cnt.p, cnt.size() * sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     std::vector<WorkItem> &items = ctx->h_ovf_items;
     items.clear();
     // [first, end) of track i in items of one wave each: 64 lanes x redo_lane_frames(step) positions
-    auto add_range = [&](size_t i, uint64_t first, uint64_t end) {
+    // (chan0: the first channel of the pair the redo covers -- k_true_peak_rows takes it from the high half of item.pad)
+    auto add_range = [&](size_t i, uint64_t first, uint64_t end, uint32_t chan0) {
         const uint64_t per_wave = 64ull * redo_lane_frames(static_cast<uint32_t>(ctx->rates_h[g.descs[i].rate_idx].swr_step));
         for (uint64_t n = first; n < end; n += per_wave)
-            items.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min(per_wave, end - n)), n});
+            items.push_back({static_cast<uint32_t>(i), static_cast<uint32_t>(std::min(per_wave, end - n)) | chan0 << 16, n});
     };
     size_t fmt_end[3];  // f32 items first, then s16, then s24
     for (int f = 0; f < 3; f++) {
         // whole tracks: everything the fused kernel screened
         for (size_t i = 0; i < nt; i++)
-            if (ctx->h_ftp[i] && (ovf[i] & 1u) && g.fmts[i] == f) add_range(i, 0, ctx->h_fend[i]);
+            if (ctx->h_ftp[i] && (ovf[i] & 1u) && g.fmts[i] == f)
+                for (uint32_t c0 = 0; c0 + 1 < std::max<uint32_t>(g.descs[i].ch, 2); c0 += 2) add_range(i, 0, ctx->h_fend[i], c0);
         // single waves (their rows start at multiples of the resampler's input step: run_measure)
-        for (size_t w = 0; w < cnt.size(); w++) {
-            const FusedItem &it = ctx->h_fitems[w];
-            if (!(cnt[w] & kCandOverflowBit) || !it.n_rows || !ctx->h_ftp[it.track] || (ovf[it.track] & 1u) || g.fmts[it.track] != f) continue;
-            add_range(it.track, it.frame0, std::min<uint64_t>(it.frame0 + static_cast<uint64_t>(it.n_rows) * it.row_len, ctx->h_fend[it.track]));
-        }
+        for (const auto &run : ctx->h_runs)
+            for (size_t w = 0; w < run.n_items * run.wpi && run.list_off + w < cnt.size(); w++) {
+                const FusedItem &it = ctx->h_fitems[run.item_off + w / run.wpi];
+                if (!(cnt[run.list_off + w] & kCandOverflowBit) || !it.n_rows || !ctx->h_ftp[it.track] || (ovf[it.track] & 1u) || g.fmts[it.track] != f) continue;
+                add_range(it.track, it.frame0, std::min<uint64_t>(it.frame0 + static_cast<uint64_t>(it.n_rows) * it.row_len, ctx->h_fend[it.track]),
+                          static_cast<uint32_t>(2 * (w % run.wpi)));
+            }
         fmt_end[f] = items.size();
     }
     if (std::getenv("HR_DEBUG")) {
@@ -915,6 +973,26 @@ bool fused_s16(const hr_ctx *ctx, const hr_track &t, const void *dev)
     return has_tiles && (reinterpret_cast<uintptr_t>(dev) & 15) == 0;
 }
 
+// A 5.1 / 7.1 track of f32 / s16 / s24 samples is read directly by the fused kernel (hr_kernels_fused_mc.hip: a workgroup of
+// channels / 2 waves shares the rows' pieces) when its rate's tile shape has a build, its rows start on dwords and its buffer on
+// a 16-byte boundary.  Everything else of more than two channels goes through stereo planes (splits()), as all of it did
+// until round 3; hr_config.engine = 5 keeps it that way (A/B and tests).
+bool fused_mc(const hr_ctx *ctx, const hr_track &t, const void *dev)
+{
+    if (t.channels != 6 && t.channels != 8) return false;
+    if (t.fmt != HR_FMT_F32 && t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) return false;
+    if (ctx->cfg.engine == 1 || ctx->cfg.engine == 5 || ctx->split || (ctx->no_s16_direct && t.fmt != HR_FMT_F32)) return false;
+    if (ctx->cfg.tp_mode != HR_TP_SWR192K && ctx->cfg.tp_mode != HR_TP_BS1770) return false;
+    const uint64_t hop = t.sample_rate / 10, fb = fmt_bytes(t.fmt) * t.channels;
+    if (hop < 64 || t.frames / hop < 2 || hop * fb * 64 >= 0xffffffffull || (hop * fb) % 4) return false;
+    const RateTables *rt = rate_tables(t.sample_rate);
+    if (!rt) return false;
+    const bool bs = ctx->cfg.tp_mode == HR_TP_BS1770;
+    if (bs ? rt->bs_atab.empty() : rt->tp_atab.empty()) return false;
+    const int mt = bs ? rt->bs_mt : rt->tp_mt, last_rows = (bs ? rt->bs_max_out : rt->tp_max_out) - 32 * (mt - 1);
+    return fused_mc_supported(t.channels, t.fmt, fused_tp_class(mt, last_rows)) && (reinterpret_cast<uintptr_t>(dev) & 15) == 0;
+}
+
 // A track in device memory whose address keeps it off the fast kernels (stereo f32 needs 16-byte alignment for the
 // piece DMA, integer PCM 4-byte alignment for the plane split) is copied, device to device, into the group's staging
 // buffer like a host track: one extra read and write of its bytes instead of the generic f64 kernels, which are two
@@ -931,9 +1009,11 @@ bool restaged(const hr_ctx *ctx, const hr_track &t)
 }
 bool on_device(const hr_ctx *ctx, const hr_track &t) { return (t.flags & HR_TRACK_DEVICE_PCM) && !restaged(ctx, t); }
 
-bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = nullptr)
+bool splits(const hr_ctx *ctx, const hr_track &t, const void *dev_or_null = nullptr, bool need_peaks = true)
 {
     const uint32_t hop = t.sample_rate / 10;
+    // (the direct read of 5.1 / 7.1 is a build of the full pass only: hr_block_energies, which asks for no peaks, keeps the planes)
+    if (need_peaks && fused_mc(ctx, t, on_device(ctx, t) ? t.pcm : dev_or_null)) return false;
     if (ctx->no_alloc) return false;  // the planes would need a PCM-sized buffer: such tracks take the generic kernels there
     if (ctx->cfg.engine == 1 || hop < 64 || t.frames / hop < 2 || hop * 8ull * 64 >= 0xffffffffull) return false;
     if (t.fmt != HR_FMT_F32 && t.fmt != HR_FMT_S16 && t.fmt != HR_FMT_S24) return false;
@@ -1068,7 +1148,7 @@ try {
     *out = nullptr;
     hr_config c{};
     if (cfg) c = *cfg;
-    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 4) return HR_ERR_INVALID;
+    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 5) return HR_ERR_INVALID;
     const int n = hr_device_count();
     if (n <= 0) return HR_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;
@@ -1198,10 +1278,15 @@ try {
 int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out)
 try {
     if (!ctx || !track || !out) return HR_ERR_INVALID;
-    if (!(track->flags & HR_TRACK_DEVICE_PCM)) return HR_ERR_INVALID;  // a host buffer would need a staging allocation
+    std::memset(out, 0, sizeof *out);
+    out->integrated_lufs = out->true_peak_dbtp = out->rel_threshold_lufs = -std::numeric_limits<double>::infinity();
+    out->loudness_range_lu = out->lra_low_lufs = out->lra_high_lufs = out->lra_threshold_lufs = out->max_momentary_lufs =
+        out->max_shortterm_lufs = std::numeric_limits<double>::quiet_NaN();
+    auto fail = [&](int rc) { out->status = rc; return rc; };  // (a rejected call says so in the result record too)
+    if (!(track->flags & HR_TRACK_DEVICE_PCM)) return fail(HR_ERR_INVALID);  // a host buffer would need a staging allocation
     std::lock_guard<std::mutex> lk(ctx->mu);
     const int v = validate_track(ctx, *track);
-    if (v) return v;
+    if (v) return fail(v);
     const uint32_t hop = track->sample_rate / 10;
     const uint64_t hops = track->frames / hop;
     if (hops * track->channels > HR_NOALLOC_MAX_HOP_CHANNELS) {
@@ -1209,14 +1294,33 @@ try {
                              "static workspace); use hr_analyze_batch\n",
                      static_cast<unsigned long long>(hops), static_cast<unsigned>(track->channels),
                      static_cast<unsigned>(HR_NOALLOC_MAX_HOP_CHANNELS), kScratchBytes);
-        return HR_ERR_TOO_LARGE;
+        return fail(HR_ERR_TOO_LARGE);
+    }
+    // Everything the call will carve from the array, bounded from above BEFORE anything is queued: records, hop sums, block
+    // powers, the two histograms, candidate lists (4 KiB per fused wave), and the work-item lists, which grow with the
+    // FRAMES (one item per 8192 positions for the generic peak kernels and, worst case, for the exact redo of every fused
+    // wave), not with the hops -- a mono or multichannel track at 384 / 768 kHz inside the hop limit is far longer in frames.
+    {
+        const uint64_t ch = track->channels, waves = (hops / 64 + 8) * std::max<uint64_t>(1, ch / 2), per_span = track->frames / kPeakSpan + hops / 256 + 16;
+        const uint64_t need = (hops + kPreRec + 8) * ch * sizeof(HopRec) + (hops + kPreHop + 8) * ch * sizeof(double) + (hops + 1) * sizeof(double) +
+                              2 * kEbuBins * sizeof(uint32_t) + waves * (fused_cand_bytes(1) + sizeof(FusedItem) + sizeof(unsigned)) +
+                              (2 * per_span + 2 * ch) * sizeof(WorkItem) + (hops * ch / 256 + 2) * sizeof(WorkItem) +
+                              (hops / kGateChunk + 2) * (sizeof(WorkItem) + sizeof(GatePart)) + sizeof(TrackDesc) + sizeof(TrackOut) + 4096 +
+                              32 * 256 /* every buffer starts on a 256-byte boundary */;
+        if (need > kScratchBytes) {
+            std::fprintf(stderr, "headroom_hip: hr_analyze_device_noalloc: this track would need %llu bytes of workspace, the static array "
+                                 "holds %zu (%llu frames x %u channels: the work-item lists grow with the frames); use hr_analyze_batch\n",
+                         static_cast<unsigned long long>(need), kScratchBytes, static_cast<unsigned long long>(track->frames),
+                         static_cast<unsigned>(track->channels));
+            return fail(HR_ERR_TOO_LARGE);
+        }
     }
     // the rate's device tables are allocated when a rate is first seen: that must have happened in an earlier, ordinary call
     bool resident = false;
     for (uint32_t fs : ctx->rate_fs) resident |= fs == track->sample_rate;
-    if (!resident) return HR_ERR_NOT_READY;
+    if (!resident) return fail(HR_ERR_NOT_READY);
     const int dev = ctx->cfg.device;
-    if (dev >= kMaxDevices || !g_scratch_ptr[dev]) return HR_ERR_HIP;
+    if (dev >= kMaxDevices || !g_scratch_ptr[dev]) return fail(HR_ERR_HIP);
     HIPCHK(hipSetDevice(dev));
     std::lock_guard<std::mutex> lk_dev(g_scratch_mu[dev]);
     Arena arena;
@@ -1236,16 +1340,16 @@ try {
         }
         ~Swap()
         {
+            // Whatever way the call is left (an error after kernels were queued included), nothing may still be reading or
+            // writing the array when the per-GPU lock is released: the next caller carves the same bytes.
+            (void)hipStreamSynchronize(ctx->stream);
+            if (ctx->side) (void)hipStreamSynchronize(ctx->side);
             ctx->no_alloc = false;
             for (size_t i = 0; i < ws.size(); i++) *ws[i] = saved[i];
         }
     } swap(ctx, &arena);
     ctx->shard_open = false;  // an open time shard's workspace is not the one pass 2 would find
     ctx->last_total_ms = ctx->last_main_ms = 0;
-    std::memset(out, 0, sizeof *out);
-    out->integrated_lufs = out->true_peak_dbtp = out->rel_threshold_lufs = -std::numeric_limits<double>::infinity();
-    out->loudness_range_lu = out->lra_low_lufs = out->lra_high_lufs = out->lra_threshold_lufs = out->max_momentary_lufs =
-        out->max_shortterm_lufs = std::numeric_limits<double>::quiet_NaN();
     int rc = analyze_group(ctx, track, std::vector<size_t>{0}, out);
     if (rc == HR_ERR_OOM) rc = HR_ERR_TOO_LARGE;  // the array was too small after all (the limit above is meant to exclude this)
     if (rc) out->status = rc;
@@ -1270,7 +1374,7 @@ try {
         dev = ctx->stage.p;
         if (bytes) HIPCHK(hipMemcpyAsync(ctx->stage.p, track->pcm, bytes, hipMemcpyHostToDevice, st));
     }
-    const bool sp = splits(ctx, *track);
+    const bool sp = splits(ctx, *track, nullptr, false);
     if (sp && !ctx->widened.ensure(split_bytes(*track))) return HR_ERR_OOM;
     const int own = add_track(ctx, g, *track, dev, ctx->widened.as<float>(), sp);
     if (own < 0) return own;

@@ -26,7 +26,9 @@ __host__ __device__
 #endif
 inline uint32_t redo_lane_frames(uint32_t step) { return step * ((128u + step - 1u) / step); }
 constexpr uint32_t kCandOverflowBit = 0x80000000u;  // in a wave's candidate count: its list ran out of slots
-constexpr uint32_t kGateChunk = 16384;  // 400 ms blocks (and 3 s windows) per gating workgroup: a 3-minute track is one chunk
+// 400 ms blocks (and 3 s windows) per gating workgroup: a 3-minute track (1797 blocks) is one chunk, a 10-hour stream 176 --
+// with 16 384 (rounds 1, 2) that stream kept 22 of the 256 CUs busy for 1.5 ms (profiles/r3_config5_kernel_stats.md)
+constexpr uint32_t kGateChunk = 2048;
 
 // what one gating chunk hands to the per-track finalisation (summed there in chunk order: reproducible)
 struct GatePart {

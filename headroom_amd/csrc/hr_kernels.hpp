@@ -56,10 +56,21 @@ struct FusedScratch {
 };
 size_t fused_cand_bytes(uint32_t n_items);
 // Exact true peak (the context's bank, exact phase counts only) of ranges of stereo f32 / s16 / s24 tracks: an item is one
-// wave, item.first its first position (a multiple of the resampler's input step), item.pad its positions
-// (<= 64 * redo_lane_frames(step)).  The redo of fused waves whose candidate lists overflowed.
+// wave, item.first its first position (a multiple of the resampler's input step), the low 16 bits of item.pad its positions
+// (<= 64 * redo_lane_frames(step)), the high 16 bits the first channel of the pair it covers (0 for a stereo track; tracks of
+// more channels go frame by frame).  The redo of fused waves whose candidate lists overflowed.
 void launch_true_peak_rows(int fmt, const TrackDesc *tracks, const RateDev *rates, const WorkItem *items, uint32_t n_items,
                            unsigned long long *peaks, hipStream_t st);
+// exact evaluation of the candidate lists of a fused launch: n_lists lists, wpi of them per item (1: stereo; channels / 2: a
+// multichannel track read directly, list w of an item being channels 2 w and 2 w + 1)
+void launch_refine_cands(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_lists, uint32_t wpi,
+                         const FusedScratch &fs, unsigned long long *peaks, hipStream_t st);
+// hr_kernels_fused_mc.hip: the fused pass on interleaved 5.1 / 7.1 tracks read directly (one item = 64 rows of ALL channels, a
+// workgroup of channels / 2 waves; fs.cands / fs.cand_cnt hold channels / 2 lists per item).  fused_mc_supported: is there a
+// build for this channel count, sample format (HR_FMT_F32 / S16 / S24) and true-peak class?
+bool fused_mc_supported(int channels, int fmt, int tp_class);
+void launch_fused_mc(int channels, int fmt, int tp_class, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
+                     uint32_t n_items, HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, hipStream_t st);
 // All items of one launch share a true-peak class (the kernel is specialised on the tile shape of the rate).
 int fused_tp_class(int tp_mt, int tp_last_rows);
 void launch_fused_f32s(const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,

@@ -338,6 +338,26 @@ __device__ __forceinline__ int ebu_bin_from_edges(const double *__restrict__ edg
     return lo;
 }
 
+// One count for bin `bin` (a negative bin: none) into a workgroup's histogram.  Lanes of a wave that hit the same bin are
+// combined first -- a long steady stream puts every block into the same two or three bins -- in up to four rounds (the bin of
+// the first pending lane each time); lanes still pending after that add their own.  Integer counts: the result does not
+// depend on the order.
+__device__ __forceinline__ void hist_add_wave(uint32_t *hg, int bin)
+{
+    bool pending = bin >= 0;
+    for (int round = 0; round < 4; round++) {
+        const unsigned long long live = __ballot(pending);
+        if (live == 0ull) return;
+        const int leader = __ffsll(static_cast<long long>(live)) - 1;
+        const int b = __shfl(bin, leader, 64);
+        const bool mine = pending && bin == b;
+        const unsigned long long same = __ballot(mine);
+        if (static_cast<int>(threadIdx.x & 63) == leader) atomicAdd(&hg[b], static_cast<uint32_t>(__popcll(same)));
+        pending = pending && !mine;
+    }
+    if (pending) atomicAdd(&hg[bin], 1u);
+}
+
 __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
                                                     int gate_mode, const double *__restrict__ hop_sums,
                                                     const double *__restrict__ ln_bounds,
@@ -345,12 +365,19 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
                                                     double *__restrict__ block_powers,
                                                     uint32_t *__restrict__ hist, GatePart *__restrict__ parts)
 {
+    // The chunk's histogram is built in LDS and joins the track's afterwards, one atomic per bin the chunk touched: every
+    // increment of a bin in global memory is a read-modify-write at the L2, and the 176 chunks of a steady 10-hour stream
+    // all want the same two or three bins (round 3: 1.15 ms of a 5.5 ms call, profiles/r3_config5_kernel_stats.md).
+    __shared__ uint32_t hh[kEbuBins];
     __shared__ double shd[256];
     __shared__ unsigned long long shu[256];
     const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first block of the chunk
     const TrackDesc &t = tracks[it.track];
     const int C = t.ch;
     uint32_t *hg = hist + static_cast<size_t>(it.track) * kEbuBins;  // zeroed by the host before the launch
+    const int nbins = gate_mode == 2 ? kLnBins : gate_mode == 0 ? kEbuBins : 0;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
+    __syncthreads();
 
     const double bins = gate_mode == 2 ? static_cast<double>(4 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
                                        : static_cast<double>(static_cast<uint64_t>(t.fs) * 4 / 10);
@@ -359,38 +386,48 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
     unsigned long long n_kept = 0;
     const double *H = hop_sums + t.hop_base + kPreHop * C;
     const uint64_t jj_end = it.first + kGateChunk < t.n_blocks ? it.first + kGateChunk : t.n_blocks;
-    for (uint64_t jj = it.first + threadIdx.x; jj < jj_end; jj += blockDim.x) {
-        const int64_t j = t.blk_first + static_cast<int64_t>(jj);
-        double power = gate_mode == 2 ? 0.0 : 1e-12;
-        for (int c = 0; c < C; c++) {
-            if (t.w[c] == 0.0f) continue;
-            const double s = ((H[j * C + c] + H[(j + 1) * C + c]) + H[(j + 2) * C + c]) + H[(j + 3) * C + c];
-            power += static_cast<double>(t.w[c]) * s;
-        }
-        power /= bins;
-        block_powers[t.blk_base + jj] = power;
-        if (gate_mode == 0) {
-            // loud = -0.691 + 10 log10(power) >= -70 and its bin, decided on the power itself (ebur128_bin_edges)
-            if (power >= ebu_edges[0]) {
-                atomicAdd(&hg[ebu_bin_from_edges(ebu_edges, power)], 1u);
-                sum_kept += power;
-                n_kept++;
+    // (every lane of the workgroup runs every trip of the loop -- lanes past the chunk's end with nothing to add -- so that
+    // the wave-wide combination of the histogram counts sees whole waves)
+    for (uint64_t j0 = it.first; j0 < jj_end; j0 += blockDim.x) {
+        const uint64_t jj = j0 + threadIdx.x;
+        int bin = -1;
+        if (jj < jj_end) {
+            const int64_t j = t.blk_first + static_cast<int64_t>(jj);
+            double power = gate_mode == 2 ? 0.0 : 1e-12;
+            for (int c = 0; c < C; c++) {
+                if (t.w[c] == 0.0f) continue;
+                const double s = ((H[j * C + c] + H[(j + 1) * C + c]) + H[(j + 2) * C + c]) + H[(j + 3) * C + c];
+                power += static_cast<double>(t.w[c]) * s;
             }
-        } else if (gate_mode == 2) {
-            if (power >= ln_bounds[0]) {
-                int lo = 0, hi = kLnBins;
-                do {
-                    const int mid = (lo + hi) / 2;
-                    if (power >= ln_bounds[mid]) lo = mid; else hi = mid;
-                } while (hi - lo != 1);
-                atomicAdd(&hg[lo], 1u);
-                sum_kept += power;
-                n_kept++;
+            power /= bins;
+            block_powers[t.blk_base + jj] = power;
+            if (gate_mode == 0) {
+                // loud = -0.691 + 10 log10(power) >= -70 and its bin, decided on the power itself (ebur128_bin_edges)
+                if (power >= ebu_edges[0]) {
+                    bin = ebu_bin_from_edges(ebu_edges, power);
+                    sum_kept += power;
+                    n_kept++;
+                }
+            } else if (gate_mode == 2) {
+                if (power >= ln_bounds[0]) {
+                    int lo = 0, hi = kLnBins;
+                    do {
+                        const int mid = (lo + hi) / 2;
+                        if (power >= ln_bounds[mid]) lo = mid; else hi = mid;
+                    } while (hi - lo != 1);
+                    bin = lo;
+                    sum_kept += power;
+                    n_kept++;
+                }
+            } else {
+                if (power > abs_exact) { sum_kept += power; n_kept++; }
             }
-        } else {
-            if (power > abs_exact) { sum_kept += power; n_kept++; }
         }
+        if (gate_mode != 1) hist_add_wave(hh, bin);
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x)
+        if (hh[i]) atomicAdd(&hg[i], hh[i]);
     const double sk = block_reduce_sum(sum_kept, shd);
     const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
     if (threadIdx.x == 0) {

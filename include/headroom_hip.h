@@ -72,7 +72,9 @@ typedef struct hr_config {
     int32_t engine;     /* 0 = default (fastest available), 1 = force the generic kernels;
                            2 / 3 / 4 = the fast kernels with rows of a whole hop only / of a fraction of a hop wherever
                            a track allows it / of a fraction of a hop for the hops that do not fill a wave (0 chooses
-                           per track and launch; same results, for tests and timing) */
+                           per track and launch; same results, for tests and timing); 5 = as 0, but 5.1 / 7.1 tracks are
+                           split into stereo planes first instead of being read directly (the path of rounds 1-2; same
+                           results bit for bit, for tests and A/B timing) */
     void *stream;       /* hipStream_t to run on, or NULL for a stream owned by the context */
     uint64_t stage_bytes; /* device staging for host-resident PCM; 0 = default (1 GiB)      */
 } hr_config;
@@ -132,18 +134,23 @@ void hr_free_pinned(void *p);
  * fail the batch (src/cli.rs:419-430).  Thread-safe per context (serialised internally). */
 int hr_analyze_batch(hr_ctx *ctx, const hr_track *tracks, size_t n, hr_result *out);
 
-/* hr_analyze_batch for ONE track that is already in HBM, without any allocation.  No counterpart in the reference: it is
- * for callers that cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid
- * hipMalloc.  The entry point calls no hipMalloc / hipFree and no allocating library routine: all device workspace
- * (zero-state records, hop sums, block powers, histograms, candidate lists, work items) is carved from ONE static
- * device array of 8 MiB inside the library, which every GPU the library runs on holds until the process ends.
+/* hr_analyze_batch for ONE track that is already in HBM, without any device or pinned allocation.  No counterpart in the
+ * reference: it is for callers that cannot allocate device memory -- tight serving loops, harnesses that forbid hipMalloc,
+ * processes whose memory is fully budgeted.  The entry point calls no hipMalloc / hipFree / hipHostMalloc and no library
+ * routine that does: all device workspace (zero-state records, hop sums, block powers, histograms, candidate lists, work
+ * items) is carved from ONE static device array of 16 MiB inside the library, which every GPU the library runs on holds
+ * until the process ends.  It is NOT a graph-capturable call: like hr_analyze_batch it copies its few hundred bytes of
+ * results back to the host, synchronises the context's stream before it returns, and uses ordinary host containers
+ * (std::vector) for its launch descriptors.
  * Requirements: track->flags has HR_TRACK_DEVICE_PCM (else HR_ERR_INVALID); hops x channels, hops = frames /
- * (sample_rate / 10), at most HR_NOALLOC_MAX_HOP_CHANNELS (else HR_ERR_TOO_LARGE; stereo: 54 minutes); the context
- * has already seen this sample rate in an ordinary call, which is when the rate's tables are allocated (else
- * HR_ERR_NOT_READY).  Tracks that hr_analyze_batch would first split into stereo planes (mono, 5.1, 7.1) take the
- * generic kernels here: same results, slower.  Calls on one GPU share that GPU's array (it keeps the last call's
- * contents; everything that must start at zero is cleared per call) and are serialised by a per-GPU lock inside the
- * library; results are those of hr_analyze_batch. */
+ * (sample_rate / 10), at most HR_NOALLOC_MAX_HOP_CHANNELS (stereo: 54 minutes), and a workspace estimate -- which also
+ * grows with frames / 8192, so very high sample rates reach it first -- that fits the array, both checked before anything
+ * is queued (else HR_ERR_TOO_LARGE); the context has already seen this sample rate in an ordinary call, which is when the
+ * rate's tables are allocated (else HR_ERR_NOT_READY).  Tracks that hr_analyze_batch would first split into stereo planes
+ * (mono, 5.1, 7.1) take the generic kernels here: same results, slower.  Calls on one GPU share that GPU's array (it keeps
+ * the last call's contents; everything that must start at zero is cleared per call) and are serialised by a per-GPU lock
+ * inside the library, which is released only once the context's streams have drained; results are those of
+ * hr_analyze_batch. */
 #define HR_NOALLOC_MAX_HOP_CHANNELS 65536u
 int hr_analyze_device_noalloc(hr_ctx *ctx, const hr_track *track, hr_result *out);
 

@@ -1,5 +1,5 @@
 """The code BASELINE config 5 (one 10-hour stream, 360 000 blocks) really runs, against the oracle: gating and range
-statistics in SEVERAL chunks of kGateChunk = 16384 blocks (k_block_hist with n_parts > 1, the chunk-order partial sums
+statistics in SEVERAL chunks of kGateChunk blocks (2048; 16384 until round 3: the stream keeps its length, 27 chunks now) (k_block_hist with n_parts > 1, the chunk-order partial sums
 of k_gate_final, the chunked k_range_stats / k_range_final), on one whole track and on the same stream as three time
 shards of more than one chunk each.  8 kHz keeps 54 000 hops at 43 M frames; HR_TP_SAMPLE keeps the oracle fast (the
 peak path does not depend on the chunking)."""
@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 GATES = {"ebur128": 0, "exact": 1, "loudnorm": 2}
 FS = 8000
 HOP = FS // 10
-CHUNK = 16384  # hr_device.hpp kGateChunk
+CHUNK = 16384  # (what hr_device.hpp kGateChunk was when the stream's length was chosen; every multiple of today's 2048)
 RANGE_KEYS = (("loudness_range_lu", "lra"), ("lra_low_lufs", "lra_low"), ("lra_high_lufs", "lra_high"),
               ("lra_threshold_lufs", "lra_threshold"), ("max_momentary_lufs", "max_momentary"),
               ("max_shortterm_lufs", "max_shortterm"))

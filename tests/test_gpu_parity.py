@@ -724,6 +724,44 @@ def test_largest_sample_near_the_end_other_rates(oracle, meters, fs, ragged):
     end_of_track_cases(oracle, meters(tp="swr192k"), fs, ragged, "swr192k", "f32")
 
 
+@pytest.mark.parametrize("case", ["s16_44k", "s24_44k", "f32_22k", "s16_44k_odd_hops", "s24_44k_ragged8"])
+def test_device_tracks_whose_last_row_is_off_the_16_byte_grid(oracle, meters, case):
+    """Rows of the fused kernel start on a 16-byte boundary of the track's image only when hop x frame bytes is a multiple of
+    16: not at 44.1 kHz s16 (17 640 bytes: every other row starts 8 bytes in), 44.1 kHz s24 (26 460: 12 bytes in), nor at
+    odd hop lengths (22.05 kHz f32).  The DMA's 16-byte chunks count from the ROW's start, so a final row may be fused only
+    when the track ends on ITS chunk grid (the host tested the track's own grid, and the last chunk of such a row
+    read 8 / 12 bytes past the caller's buffer).  Device tracks that end exactly with their allocation, in the geometries
+    that decide differently now; the numbers must be the oracle's either way."""
+    import torch
+    fs, kind, frames = {"s16_44k": (44100, "s16", 4410 * 20),            # even hop count, frames % 4 == 0: row 19 starts 8 bytes in
+                        "s24_44k": (44100, "s24", 4410 * 20),            # frames % 8 == 0: row 19 starts 12 bytes in
+                        "f32_22k": (22050, "f32", 2205 * 20),            # odd hop length: every other row starts 8 bytes in
+                        "s16_44k_odd_hops": (44100, "s16", 4410 * 21 + 2),  # the last row starts on the grid, the track ends off it
+                        "s24_44k_ragged8": (44100, "s24", 4410 * 21 + 8)}[case]
+    pcm = signals.seeded_noise(77 + frames, frames, 2, -12.0)
+    pcm[frames - 3, 0] = 0.97   # the largest sample sits in the last chunk of the track
+    pcm[frames - 20, 1] = -0.95
+    if kind == "s16":
+        host = signals.to_s16(pcm)
+        dev = torch.from_numpy(host.reshape(-1)).cuda()
+        spec = hr.TrackSpec(dev.data_ptr(), fs, channels=2, fmt=hr.FMT_S16, frames=frames)
+        ref = oracle.measure(host, fs)
+    elif kind == "s24":
+        host = signals.to_s24_bytes(pcm)
+        dev = torch.from_numpy(host.reshape(-1)).cuda()
+        spec = hr.TrackSpec(dev.data_ptr(), fs, channels=2, fmt=hr.FMT_S24, frames=frames)
+        ref = oracle.measure(host, fs, channels=2, fmt=hr.FMT_S24)
+    else:
+        dev = torch.from_numpy(pcm).cuda()
+        spec = hr.TrackSpec(dev.data_ptr(), fs, channels=2, fmt=hr.FMT_F32, frames=frames)
+        ref = oracle.measure(pcm, fs)
+    for engine in (0, 2, 3):
+        got = meters(engine=engine).analyze_batch([spec])[0]
+        assert got["status"] == 0 and got["n_blocks"] == ref["n_blocks"] and got["n_gated"] == ref["n_gated"]
+        assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6, (engine, got, ref)
+        assert got["peak_per_ch"] == ref["peak_per_ch"], (engine, got, ref)
+
+
 def test_misaligned_device_tracks_are_restaged(oracle, meters):
     """Device PCM at an address the fast kernels cannot take (stereo f32 off the 16-byte grid, integer PCM off the dword
     grid) is copied into the staging buffer instead of falling to the generic kernels: same numbers, and the fused

@@ -38,7 +38,17 @@ def device_track(m, seed, fs, ch, frames):
     return t
 
 
+def against_oracle(got, pcm, fs, **kw):
+    """The entry point's own result against the CPU oracle, to the bar of tests/test_gpu_parity.py."""
+    import oracle_lib
+    ref = oracle_lib.measure(pcm, fs, **kw)
+    assert got["n_blocks"] == ref["n_blocks"] and got["n_gated"] == ref["n_gated"], (got, ref)
+    assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6, (got, ref)
+    assert got["peak_per_ch"] == ref["peak_per_ch"], (got, ref)  # bit-identical f64
+
+
 def test_noalloc_matches_batch_twice_second_smaller():
+    import torch
     fs = 44100
     with hr.Meter(device=0) as m:
         big = device_track(m, 9001, fs, 2, fs * 31 + 777)     # 310 hops: five waves of the fused kernel, a ragged tail
@@ -46,9 +56,15 @@ def test_noalloc_matches_batch_twice_second_smaller():
         for t in (big, small):                                 # the second call finds the first one's contents in the array
             spec = hr.TrackSpec(t, fs)
             ref = m.analyze_batch([spec])[0]
+            # the property the entry point exists for: the call takes no device memory (and gives none back)
+            torch.cuda.synchronize()
+            free_before = torch.cuda.mem_get_info(0)[0]
             rc, got = m.analyze_device_noalloc(spec)
+            free_after = torch.cuda.mem_get_info(0)[0]
             assert rc == hr.OK, rc
+            assert free_after == free_before, (free_before, free_after)
             same(got, ref)
+            against_oracle(got, t.cpu().numpy(), fs)
         # and once more the other way round (a larger input after a smaller one: every buffer is carved again)
         spec = hr.TrackSpec(big, fs)
         rc, got = m.analyze_device_noalloc(spec)
@@ -114,3 +130,30 @@ def test_noalloc_rejections():
         same(r, ref)
         # the context's own workspace is untouched by all this
         same(m.analyze_batch([spec])[0], m.analyze_device_noalloc(spec)[1])
+
+
+def test_noalloc_limits_that_grow_with_frames():
+    """The work-item lists grow with the frames, not the hops: a high-rate mono track inside the hop limit is rejected up
+    front when its estimate passes the array (nothing is queued: the pointer is never read), and a full-scale tone -- every
+    fused wave is redone exactly, the worst case of the redo list -- is served."""
+    import torch
+    with hr.Meter(device=0) as m:
+        fs = 768000
+        z = torch.zeros((fs, 1), dtype=torch.float32, device="cuda:0")
+        m.analyze_batch([hr.TrackSpec(z, fs)])  # (the rate's tables become resident)
+        hops = 60000  # inside the hop x channel limit, 4.6e9 frames
+        rc, r = m.analyze_device_noalloc(hr.TrackSpec(z.data_ptr(), fs, channels=1, fmt=hr.FMT_F32, frames=hops * (fs // 10)))
+        assert rc == hr.ERR_TOO_LARGE and r["status"] == hr.ERR_TOO_LARGE
+        rc, r = m.analyze_device_noalloc(hr.TrackSpec(z, fs))
+        assert rc == hr.OK
+        same(r, m.analyze_batch([hr.TrackSpec(z, fs)])[0])
+        fs = 48000
+        n = fs * 600
+        tt = torch.arange(n, dtype=torch.float64, device="cuda:0")
+        tone = torch.sin(tt * (2 * math.pi * 997.0 / fs)).to(torch.float32)
+        pcm = torch.stack([tone, 0.5 * tone], dim=1).contiguous()
+        spec = hr.TrackSpec(pcm, fs)
+        ref = m.analyze_batch([spec])[0]
+        rc, r = m.analyze_device_noalloc(spec)
+        assert rc == hr.OK
+        same(r, ref)
