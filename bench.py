@@ -60,14 +60,24 @@ def cpu_baseline(n_tracks, threads):
                       f"one thread per track, oracle mode ebur128 gating + 192 kHz interpolation, {dt:.2f} s wall"}, res, tracks
 
 
+PROFILES = os.path.join(ROOT, "profiles")
+
+
 def valu_ceiling(bytes_per_step, kernel_ms):
-    """SURVEY 8(d) "min(HBM, VALU)": what the vector ALU lets the fused kernel reach, beside the HBM fraction.  The
-    per-sample instruction counts and the clock are the committed measurements of profiles/README.md (round 2: ISA count
-    of the hot block, SQ_ACTIVE_INST_VALU and GRBM_GUI_ACTIVE passes on a 200-track launch); a full-rate VALU
-    instruction occupies a SIMD for 4 cycles per 64-lane wave (profiles/r1_microbench2.txt: 2.2-2.6 ns per f64 FMA)."""
+    """SURVEY 8(d) "min(HBM, VALU)": what the vector ALU lets the fused kernel reach, beside the HBM fraction.  Everything
+    here except `frac_of_valu_ceiling` is read from a committed PMC profile of THIS workload (profiles/valu_profile.json:
+    SQ_INSTS_VALU per sample, the clock under the kernel from GRBM_GUI_ACTIVE), not measured in this run; the caller emits
+    the block only for the configuration that profile was taken on.  A full-rate VALU instruction occupies a SIMD for 4 cycles
+    per 64-lane wave (profiles/r1_microbench2.txt: 2.2-2.6 ns per f64 FMA)."""
+    path = os.path.join(PROFILES, "valu_profile.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        prof = json.load(fh)
     simds, lanes_per_cycle = 256 * 4, 16
-    f64_ops, valu_slots = 13.0, 21.2          # per 4-byte sample: 12 f64 FMA/MUL/ADD + 1 convert; all VALU issue slots (PMC)
-    clk_obs, clk_max = 1.60e9, 2.4e9          # GRBM_GUI_ACTIVE / 8 / duration under the kernel; data-sheet maximum
+    f64_ops, valu_slots = prof["f64_ops_per_sample"], prof["valu_issue_slots_per_sample"]
+    clk_obs, clk_max = prof["clock_observed_ghz"] * 1e9, 2.4e9
+
     def gbs(ops, clk):
         return simds * lanes_per_cycle * clk / ops * 4.0 / 1e9
     return {"f64_ops_per_sample": f64_ops, "valu_issue_slots_per_sample": valu_slots, "cycles_per_wave_instruction": 4,
@@ -75,7 +85,23 @@ def valu_ceiling(bytes_per_step, kernel_ms):
             "ceiling_gbs_at_observed_clock": gbs(valu_slots, clk_obs), "ceiling_gbs_at_max_clock": gbs(valu_slots, clk_max),
             "f64_only_ceiling_gbs_at_observed_clock": gbs(f64_ops, clk_obs),
             "frac_of_valu_ceiling": (bytes_per_step / (kernel_ms * 1e-3) / 1e9) / gbs(valu_slots, clk_obs) if kernel_ms > 0 else None,
-            "source": "profiles/README.md round 2 (SQ_ACTIVE_INST_VALU, GRBM_GUI_ACTIVE passes; the kernel runs power-limited at the observed clock)"}
+            "measured_in_this_run": ["frac_of_valu_ceiling"],
+            "source": "from profile, not this run: profiles/valu_profile.json (" + prof["source"] + ")"}
+
+
+def side_roofline(nbytes, kernel_ms, traffic_file=None, what="K-weight + true-peak pass (HIP events on the library stream, mean over timed steps)"):
+    """The roofline object of a side figure: algorithmic bytes (every sample read once) over the fused kernel's own duration
+    of THIS run; `traffic` from a committed PMC pass of the same workload where one exists (labelled), else null."""
+    achieved = nbytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    traffic, src = None, None
+    if traffic_file and os.path.exists(os.path.join(PROFILES, traffic_file)):
+        with open(os.path.join(PROFILES, traffic_file)) as fh:
+            t = json.load(fh)
+        ratio = t["bytes_per_launch"] / t["algorithmic_bytes_per_launch"] if "bytes_per_launch" in t else t["bytes_per_track"] / t["algorithmic_bytes_per_track"]
+        traffic = ratio * nbytes
+        src = f"from profile, not this run: profiles/{traffic_file} (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), scaled by bytes"
+    return {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": src, "algorithmic_bytes": nbytes, "kernel": what, "kernel_ms": kernel_ms}
 
 
 def main():
@@ -100,6 +126,10 @@ def main():
                          "short-clip side figure: per-track fixed costs -- the last hop and the ragged tail -- weigh 18 times more)")
     ap.add_argument("--ragged", type=int, default=0, help="extra frames per track beyond a whole number of hops (side figures)")
     ap.add_argument("--hours", type=float, default=10.0, help="config5: length of the stream")
+    ap.add_argument("--shard-protocol", choices=["device", "host"], default="device",
+                    help="config5 with --gpus N > 1: the exchange records stay on the GPUs (one edge send / receive, one all-gather, one "
+                         "synchronisation: hr_shard_*_device) or travel as host structs (rounds 1-2: halo exchange, edge exchange, three "
+                         "all-reduces)")
     ap.add_argument("--total-tracks", type=int, default=0,
                     help="config3 with --gpus N > 1 (or this flag): the whole batch is this many tracks (default 10000 = BASELINE "
                          "configs[2]) split over the ranks by bytes, strong scaling")
@@ -145,7 +175,16 @@ def main():
         meter.close()
         return
     if args.workload == "config5":
-        run_config5(args, meter, dev, local, rank, world, rehearsal)
+        if world > 1 and args.shard_protocol == "device":
+            # the meter works on a torch stream, so that RCCL's collectives and the library's kernels are ordered on it
+            meter.close()
+            comm_stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(comm_stream):
+                meter = hr.Meter(device=local, engine=args.engine, stream=comm_stream.cuda_stream)
+                run_config5(args, meter, dev, local, rank, world, rehearsal)
+                torch.cuda.synchronize()
+        else:
+            run_config5(args, meter, dev, local, rank, world, rehearsal)
         meter.close()
         if world > 1:
             dist.destroy_process_group()
@@ -217,7 +256,8 @@ def main():
         # committed measurement (profiles/r2_fused_hbm_traffic.json, bytes per track) scaled to this launch
         traffic, traffic_src = None, None
         tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_fused_hbm_traffic.json")
-        if os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32" and SECONDS == 180 and not args.ragged:
+        if (os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32" and SECONDS == 180 and not args.ragged
+                and args.tp_mode == "swr192k"):
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_track"] * n_tracks
             traffic_src = "profiles/r2_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
@@ -236,9 +276,12 @@ def main():
                          "kernel_ms": kernel_ms},
             "hbm_gbs_whole_step": bytes_per_step * args.steps / elapsed / 1e9,
         }
-        if args.pcm_format == "f32" and args.tp_mode == "swr192k":
-            line["roofline"]["valu"] = valu_ceiling(bytes_per_step, kernel_ms)
-            line["roofline"]["binding_ceiling"] = "valu" if line["roofline"]["valu"]["ceiling_gbs_at_observed_clock"] < HBM_PEAK_GBS else "hbm"
+        # (only for the configuration the PMC profile behind it was taken on: 180 s 44.1 kHz stereo f32, libswresample's bank)
+        if traffic is not None and args.tp_mode == "swr192k":
+            valu = valu_ceiling(bytes_per_step, kernel_ms)
+            if valu:
+                line["roofline"]["valu"] = valu
+                line["roofline"]["binding_ceiling"] = "valu" if valu["ceiling_gbs_at_observed_clock"] < HBM_PEAK_GBS else "hbm"
         if (world == 1 and not args.no_cpu_baseline and args.pcm_format == "f32" and args.workload == "config2" and args.tp_mode == "swr192k"
                 and SECONDS == 180 and not args.ragged):
             # one thread per core of the job's CPU share: the scheduler's affinity mask when it is narrower than the
@@ -309,20 +352,30 @@ def run_config4(args, meter, dev, n_tracks, rank):
     del tmp
     torch.cuda.synchronize()
     specs = [hr.TrackSpec(raw[i].data_ptr(), fs, channels=ch, fmt=hr.FMT_S24, frames=frames) for i in range(n_tracks)]
+    batch = hr.TrackBatch(specs)
     for _ in range(args.warmup):
-        res = meter.analyze_batch(specs)
+        meter.analyze_prepared(batch)
     torch.cuda.synchronize()
+    kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        res = meter.analyze_batch(specs)
+        meter.analyze_prepared(batch)
+        kernel_ms.append(meter.last_timing()[1])
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
+    res = batch.results()
     assert all(r["status"] == 0 for r in res)
     nbytes = n_tracks * frames * ch * 3
+    direct = args.engine != 5
     print(json.dumps({"metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": n_tracks * SECONDS / 3600.0 / dt,
                       "unit": "audio-hours/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3,
-                      "config": {"workload": f"{n_tracks} x 180 s 96 kHz 5.1 s24 tracks resident in HBM (BASELINE configs[3]); side figure",
+                      "higher_is_better": True, "dtype": "f64", "data": "synthetic",
+                      "config": {"workload": f"{n_tracks} x 180 s 96 kHz 5.1 s24 tracks resident in HBM (BASELINE configs[3]); side figure; "
+                                             + ("18-byte frames read directly by the fused kernel" if direct else "engine 5: split into stereo planes first"),
                                  "bytes_per_gpu": nbytes},
+                      "roofline": side_roofline(nbytes, sum(kernel_ms) / len(kernel_ms), "r3_config4_hbm_traffic.json" if direct else None,
+                                                "K-weight + true-peak pass" + ("" if direct else " on the planes (the split kernels are not in this figure)")
+                                                + " (HIP events on the library stream, mean over timed steps)"),
                       "hbm_gbs_whole_step": nbytes / dt / 1e9, "sample_result": res[0]}), flush=True)
 
 
@@ -373,13 +426,24 @@ def run_config5(args, meter, dev, local, rank=0, world=1, rehearsal=False):
             meter.synth_fill(pcm.data_ptr(), 77 + rank, fs, ch, n)
             spec = hr.TrackSpec(pcm.data_ptr(), fs, channels=ch, fmt=hr.FMT_F32, frames=n)
         torch.cuda.synchronize()
-        for _ in range(args.warmup):
-            res = sharded.analyze_stream_shard(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10))
         phases = {}
+        if args.shard_protocol == "device":
+            # the 16 frames either side of a shard come with the shard (whoever cuts the stream has them): fetched once here
+            bufs = sharded.ShardBuffers(world, dev)
+            halos = sharded.shard_halos(dist, meter, spec, rank, active)
+
+            def one_call(timings=None):
+                return sharded.analyze_stream_shard_device(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10), halos=halos,
+                                                           bufs=bufs, shared_stream=not rehearsal, timings=timings)
+        else:
+            def one_call(timings=None):
+                return sharded.analyze_stream_shard(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10), timings=timings)
+        for _ in range(args.warmup):
+            res = one_call()
         _dist_barrier(world)
         t0 = time.perf_counter()
         for _ in range(args.steps):
-            res = sharded.analyze_stream_shard(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10), timings=phases)
+            res = one_call(phases)
         _dist_barrier(world)
         elapsed = _dist_max(time.perf_counter() - t0, world, rehearsal, dev)
         phase_ms = {k: _dist_max(v, world, rehearsal, dev) / args.steps * 1e3 for k, v in sorted(phases.items())}
@@ -391,7 +455,9 @@ def run_config5(args, meter, dev, local, rank=0, world=1, rehearsal=False):
                 "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                 "config": {"workload": f"one {args.hours:g} h 48 kHz stereo f32 stream time-sharded over {world} ranks, shards resident in "
                                        f"HBM (BASELINE configs[4]); side figure", "bytes_total": frames * ch * 4,
-                           "parallelism": f"time-sharded x{world}" + (" (one-device rehearsal over gloo)" if rehearsal else " over RCCL")},
+                           "parallelism": f"time-sharded x{world}" + (" (one-device rehearsal over gloo)" if rehearsal else " over RCCL"),
+                           "exchange": "records resident on the device: one edge send/receive + one all-gather per call" if args.shard_protocol == "device"
+                                       else "host records: halo exchange, edge exchange, three all-reduces per call"},
                 "phase_ms_max_over_ranks": phase_ms, "hbm_gbs_whole_step": frames * ch * 4 / dt / 1e9, "result": res}), flush=True)
         return
     pcm = torch.empty((frames, ch), dtype=torch.float32, device=dev)
@@ -404,12 +470,16 @@ def run_config5(args, meter, dev, local, rank=0, world=1, rehearsal=False):
         for _ in range(args.warmup):
             res = fn()
         torch.cuda.synchronize()
+        kernel_ms = []
         t0 = time.perf_counter()
         for _ in range(args.steps):
             res = fn()
+            kernel_ms.append(meter.last_timing()[1])
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / args.steps
         out[name] = {"ms": dt * 1e3, "audio_hours_per_s": args.hours / dt, "gb_per_s": frames * ch * 4 / dt / 1e9, "result": res}
+        if name == "whole":
+            out[name]["roofline"] = side_roofline(frames * ch * 4, sum(kernel_ms) / len(kernel_ms))
     for m in shards:
         m.close()
     a, b = out["whole"]["result"], out["sharded8"]["result"]
@@ -451,10 +521,12 @@ def run_config3_strong(args, meter, dev, rank, world, rehearsal):
         for b in launches[:1]:
             meter.analyze_prepared(b)
     _dist_barrier(world)
+    kernel_ms = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for b in launches:
             meter.analyze_prepared(b)
+            kernel_ms += meter.last_timing()[1]
     _dist_barrier(world)
     elapsed = _dist_max(time.perf_counter() - t0, world, rehearsal, dev)
     assert all(st == 0 for b in launches for st in b.statuses())
@@ -473,6 +545,8 @@ def run_config3_strong(args, meter, dev, rank, world, rehearsal):
                                    f"configs[2]); side figure", "tracks_this_rank": len(mine), "launches_this_rank": len(launches),
                        "resident_tracks_this_rank": n_res, "bytes_total": total * frames * ch * 4,
                        "parallelism": f"track-sharded x{world}" + (" (one-device rehearsal over gloo)" if rehearsal else "")},
+            "roofline": dict(side_roofline(len(mine) * frames * ch * 4, kernel_ms / args.steps, "r1_fused_hbm_traffic_48k.json"),
+                             note="rank 0's share: its bytes over the sum of its launches' fused-kernel time"),
             "hbm_gbs_whole_step": total * frames * ch * 4 / dt / 1e9}), flush=True)
 
 

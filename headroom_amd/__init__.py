@@ -21,6 +21,7 @@ TP_SWR192K, TP_BS1770, TP_SAMPLE = range(3)
 TRACK_DEVICE_PCM = 1
 OK, ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_OOM, ERR_RATE, ERR_FORMAT, ERR_TOO_LARGE, ERR_NOT_READY = 0, -1, -2, -3, -4, -5, -6, -7, -8
 NOALLOC_MAX_HOP_CHANNELS = 65536
+SHARD_AGAIN = 1
 GAIN_FFMPEG_LOSSLESS, GAIN_MP3_LOSSLESS, GAIN_MP3_REENCODE, GAIN_AAC_LOSSLESS, GAIN_AAC_REENCODE, GAIN_NONE = range(6)
 KIND_LOSSLESS, KIND_MP3, KIND_AAC = range(3)
 _FMT_BYTES = {FMT_F32: 4, FMT_S16: 2, FMT_S24: 3, FMT_S32: 4, FMT_F64: 8}
@@ -78,7 +79,8 @@ EXPORTS = ["hr_device_count", "hr_init", "hr_destroy", "hr_alloc_pinned", "hr_fr
            "hr_block_energies", "hr_analyze_stream_sharded", "hr_shard_head", "hr_shard_pass1", "hr_shard_pass2", "hr_shard_pass3", "hr_shard_finish",
            "hr_synth_fill", "hr_last_timing", "hr_strerror", "hr_gain_decision", "hr_pcm_probe", "hr_pcm_load_file",
            "hr_report_csv_header", "hr_report_csv_row", "hr_apply_gain", "hr_loudnorm_first_pass", "hr_pcm_gain_file",
-           "hr_analyze_device_noalloc", "hr_loudnorm_text_values", "hr_gain_decision_for_result"]
+           "hr_analyze_device_noalloc", "hr_loudnorm_text_values", "hr_gain_decision_for_result",
+           "hr_shard_pass1_device", "hr_shard_pass2_device", "hr_shard_redo_device", "hr_shard_finish_gathered"]
 
 _lib = None
 
@@ -118,6 +120,11 @@ def lib():
     L.hr_shard_pass3.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.POINTER(HrShardPartial)]
     L.hr_shard_finish.argtypes = [C.c_void_p, C.POINTER(HrShardPartial), C.c_int, C.POINTER(HrResult)]
     L.hr_analyze_stream_sharded.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(HrTrack), C.POINTER(HrResult)]
+    L.hr_shard_pass1_device.argtypes = [C.c_void_p, C.POINTER(HrTrack), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_int,
+                                        C.c_int, C.c_uint64, C.c_void_p]
+    L.hr_shard_pass2_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.hr_shard_redo_device.argtypes = [C.c_void_p, C.c_void_p]
+    L.hr_shard_finish_gathered.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(HrResult)]
     L.hr_pcm_probe.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(HrPcmInfo)]
     L.hr_pcm_load_file.argtypes = [C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(HrTrack), C.POINTER(C.c_float)]
     L.hr_report_csv_header.argtypes = [C.c_char_p, C.c_size_t]
@@ -362,6 +369,29 @@ class Meter:
         part = HrShardPartial()
         _check(lib().hr_shard_pass3(self._h, C.byref(reduced), C.byref(part)), "hr_shard_pass3")
         return part
+
+    # ---- the same with the records resident on the device: `edge_ptr` / `partial_ptr` / `gathered_ptr` are device addresses
+    # of the caller's buffers (sizeof(HrShardEdge) / sizeof(HrShardPartial) bytes, n partial images back to back) ----
+    def shard_pass1_device(self, spec, left_tail, right_head, first_hop, edge_ptr):
+        lp = left_tail.ctypes.data_as(C.POINTER(C.c_double)) if left_tail is not None else None
+        rp = right_head.ctypes.data_as(C.POINTER(C.c_double)) if right_head is not None else None
+        _check(lib().hr_shard_pass1_device(self._h, C.byref(spec.c), lp, rp, int(left_tail is None), int(right_head is None),
+                                           int(first_hop), C.c_void_p(int(edge_ptr))), "hr_shard_pass1_device")
+
+    def shard_pass2_device(self, left_edge_ptr, partial_ptr):
+        _check(lib().hr_shard_pass2_device(self._h, C.c_void_p(int(left_edge_ptr)) if left_edge_ptr else None,
+                                           C.c_void_p(int(partial_ptr))), "hr_shard_pass2_device")
+
+    def shard_redo_device(self, partial_ptr):
+        _check(lib().hr_shard_redo_device(self._h, C.c_void_p(int(partial_ptr))), "hr_shard_redo_device")
+
+    def shard_finish_gathered(self, gathered_ptr, n, channels):
+        """(rc, result): rc is OK or SHARD_AGAIN (every rank then runs shard_redo_device, gathers and finishes again)."""
+        r = HrResult()
+        rc = lib().hr_shard_finish_gathered(self._h, C.c_void_p(int(gathered_ptr)), n, channels, C.byref(r))
+        if rc not in (OK, SHARD_AGAIN):
+            raise HeadroomError(rc, "hr_shard_finish_gathered")
+        return rc, _result_dict(r, channels)
 
     def shard_finish(self, partial, channels):
         r = HrResult()

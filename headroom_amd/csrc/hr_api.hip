@@ -4,6 +4,9 @@
 // errors do not fail the batch) and the measurement half of analyze_file_with_target
 // (src/analyzer.rs:253-290).  There is no CPU fallback: without a HIP device hr_init fails.
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is opened at run time (RcclApi below), never linked
+
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -12,6 +15,7 @@
 #include <cstring>
 #include <new>
 #include <limits>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -150,12 +154,17 @@ struct hr_ctx {
     bool shard_pass2_done = false;  // HR_GATE_EXACT keeps the shard open from pass 2 to pass 3
     Group *shard_group = nullptr;
 
+    bool shard_device = false;      // the open shard went through the device-resident entry points (pass 2 / redo must match)
+    std::vector<double> h_halo;     // pass 1's packed halos (the source of an asynchronous upload: must outlive the call)
+    DevBuf shard_red;               // ShardReduced of hr_shard_finish_gathered
+    DevBuf shard_edge_buf, shard_left_buf, shard_part_buf, shard_gather_buf;  // hr_analyze_stream_sharded: exchange buffers of this context
     bool no_alloc = false;  // inside hr_analyze_device_noalloc: workspace comes from the static scratch array, nothing is widened
     // every grow-only workspace buffer (not the device tables)
     std::vector<DevBuf *> workspace()
     {
         return {&widened, &resampled, &parents_d, &counters, &gate_items, &gate_parts, &st_hist, &tracks_d, &items_d, &comb_items_d, &fitems_d,
-                &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos, &fp_src_d, &fp_items_d};
+                &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos, &fp_src_d, &fp_items_d,
+                &shard_red};
     }
 };
 
@@ -1201,7 +1210,8 @@ void hr_destroy(hr_ctx *ctx)
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ebu_edges, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
                       &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->comb_items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
-                      &ctx->stage, &ctx->halos, &ctx->fp_src_d, &ctx->fp_items_d})
+                      &ctx->stage, &ctx->halos, &ctx->fp_src_d, &ctx->fp_items_d, &ctx->shard_red, &ctx->shard_edge_buf, &ctx->shard_left_buf,
+                      &ctx->shard_part_buf, &ctx->shard_gather_buf})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
     delete ctx->shard_group;
@@ -1437,14 +1447,15 @@ try {
     return HR_OK;
 } HR_CATCH_ALL
 
-int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
-                   int is_last, uint64_t first_hop, hr_shard_edge *edge)
-try {
-    if (!ctx || !shard || !edge) return HR_ERR_INVALID;
-    if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
-    std::lock_guard<std::mutex> lk(ctx->mu);
-    ctx->shard_open = false;  // (set again at the end, once the new shard's workspace is complete)
+// Pass 1 up to the point where the shard's records are on their way (nothing synchronised): staging, halos, descriptor,
+// K-weighting of every hop from zero state + true peak + a first combine (the hop energies handed to the right neighbour
+// do not depend on the left edge from hop 3 on).  Caller holds ctx->mu.  *dev_out: the shard's PCM on the device.
+static int shard_pass1_core(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
+                            int is_last, uint64_t first_hop, const void **dev_out)
+{
+    ctx->shard_open = false;  // (set again by the caller, once the new shard's workspace is complete)
     ctx->shard_pass2_done = false;
+    ctx->shard_device = false;
     HIPCHK(hipSetDevice(ctx->cfg.device));
     const int v = validate_track(ctx, *shard);
     if (v) return v;
@@ -1464,7 +1475,10 @@ try {
     if (!ctx->halos.ensure(2 * kHalo * kMaxCh * sizeof(double))) return HR_ERR_OOM;
     double *halo_l = ctx->halos.as<double>(), *halo_r = halo_l + kHalo * kMaxCh;
     // the ABI hands halos over as [16][HR_MAX_CH]; the kernels read them packed [16][channels]
-    std::vector<double> packed(2 * kHalo * C, 0.0);
+    // (the packed copy lives in the context: the upload is asynchronous and the device-resident entry point does not wait)
+    HIPCHK(hipStreamSynchronize(st));  // (nothing of an earlier call may still be reading h_halo; a no-op on an idle stream)
+    std::vector<double> &packed = ctx->h_halo;
+    packed.assign(2 * kHalo * C, 0.0);
     for (int k = 0; k < kHalo; k++)
         for (int c = 0; c < C; c++) {
             if (!is_first) packed[k * C + c] = left_tail[k * HR_MAX_CH + c];
@@ -1484,8 +1498,26 @@ try {
     ctx->last_total_ms = ctx->last_main_ms = 0;
     // (the combine of pass 1 is for the hop energies handed to the right neighbour: from hop 3 on they do not depend
     // on the left edge, which only arrives for pass 2; pass 2 combines again)
-    int rc = run_measure(ctx, g, true, true);
+    const int rc = run_measure(ctx, g, true, true);
     if (rc) return rc;
+    *dev_out = dev;
+    return HR_OK;
+}
+
+int hr_shard_pass1(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
+                   int is_last, uint64_t first_hop, hr_shard_edge *edge)
+try {
+    if (!ctx || !shard || !edge) return HR_ERR_INVALID;
+    if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const void *dev = nullptr;
+    int rc = shard_pass1_core(ctx, shard, left_tail, right_head, is_first, is_last, first_hop, &dev);
+    if (rc) return rc;
+    hipStream_t st = ctx->stream;
+    const Group &g = *ctx->shard_group;
+    const int C = shard->channels;
+    const size_t fb = fmt_bytes(shard->fmt);
+    const uint64_t nh = shard->frames / (shard->sample_rate / 10);
     // right edge: last 6 hop records and the last 16 frames
     std::memset(edge, 0, sizeof *edge);
     edge->n_hops = nh;
@@ -1525,11 +1557,119 @@ try {
     return HR_OK;
 } HR_CATCH_ALL
 
+// ---- the same exchange with the records resident on the device (round 3) ---------------------------------------------------
+int hr_shard_pass1_device(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head, int is_first,
+                          int is_last, uint64_t first_hop, void *edge_dev)
+try {
+    if (!ctx || !shard || !edge_dev) return HR_ERR_INVALID;
+    if ((!is_first && !left_tail) || (!is_last && !right_head)) return HR_ERR_INVALID;
+    if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;  // (two dependent reductions: the host-record entry points serve it)
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    const void *dev = nullptr;
+    const int rc = shard_pass1_core(ctx, shard, left_tail, right_head, is_first, is_last, first_hop, &dev);
+    if (rc) return rc;
+    launch_pack_edge(ctx->tracks_d.as<TrackDesc>(), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), is_first != 0, edge_dev, ctx->stream);
+    HIPCHK(hipGetLastError());
+    ctx->shard_open = true;
+    ctx->shard_device = true;
+    return HR_OK;
+} HR_CATCH_ALL
+
+int hr_shard_pass2_device(hr_ctx *ctx, const void *left_edge_dev, void *partial_dev)
+try {
+    if (!ctx || !partial_dev) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->shard_open || !ctx->shard_device || ctx->shard_pass2_done || !ctx->shard_group) return HR_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->stream;
+    Group &g = *ctx->shard_group;
+    const TrackDesc &d = g.descs[0];
+    if ((d.blk_first < 0) != (left_edge_dev != nullptr)) return HR_ERR_INVALID;
+    if (left_edge_dev)
+        launch_unpack_edge(ctx->tracks_d.as<TrackDesc>(), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), left_edge_dev, st);
+    launch_hop_combine(ctx->tracks_d.as<TrackDesc>(), ctx->rates_d.as<RateDev>(), ctx->comb_items_d.as<WorkItem>(),
+                       static_cast<uint32_t>(ctx->comb_n), ctx->recs.as<HopRec>(), ctx->hop_sums.as<double>(), false, st);
+    int rc = run_gating(ctx, g, false, true);
+    if (rc) return rc;
+    // the screen's flags travel with the image (its `reserved`): a shard whose exact redo is pending says so to every rank,
+    // and hr_shard_finish_gathered tells the callers to run hr_shard_redo_device.  The host's copy of the flags is on its
+    // way too; it is read only after a later synchronisation.
+    rc = overflow_flags_fetch(ctx, g);
+    if (rc) return rc;
+    const int nb = ctx->cfg.gate_mode == HR_GATE_LOUDNORM ? kLnBins : kEbuBins;
+    launch_pack_partial(ctx->tracks_d.as<TrackDesc>(), ctx->hist.as<uint32_t>(), ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(),
+                        ctx->outs.as<TrackOut>(), ctx->peaks.as<unsigned long long>(), ctx->h_ovf.empty() ? nullptr : ctx->overflow.as<unsigned>(),
+                        left_edge_dev, nb, partial_dev, st);
+    HIPCHK(hipGetLastError());
+    ctx->shard_pass2_done = true;  // (the shard stays open: hr_shard_redo_device may still need its workspace)
+    return HR_OK;
+} HR_CATCH_ALL
+
+int hr_shard_redo_device(hr_ctx *ctx, void *partial_dev)
+try {
+    if (!ctx || !partial_dev) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ctx->shard_open || !ctx->shard_device || !ctx->shard_pass2_done || !ctx->shard_group) return HR_ERR_INVALID;
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->stream;
+    Group &g = *ctx->shard_group;
+    // (hr_shard_finish_gathered put its stand-in track where the shard's descriptor was)
+    int rc = upload(ctx->tracks_d, g.descs.data(), g.descs.size() * sizeof(TrackDesc), st);
+    if (rc) return rc;
+    HIPCHK(hipStreamSynchronize(st));  // the flags pass 2 asked for are in h_ovf now
+    bool relaunched = false;
+    rc = overflow_redo(ctx, g, &relaunched);
+    if (rc) return rc;
+    launch_patch_partial_peaks(ctx->tracks_d.as<TrackDesc>(), ctx->peaks.as<unsigned long long>(), partial_dev, st);
+    HIPCHK(hipGetLastError());
+    ctx->h_ovf.clear();  // (a second redo finds nothing to do)
+    return HR_OK;
+} HR_CATCH_ALL
+
+int hr_shard_finish_gathered(hr_ctx *ctx, const void *partials_dev, int n, int channels, hr_result *out)
+try {
+    if (!ctx || !partials_dev || n < 1 || !out || channels < 1 || channels > HR_MAX_CH) return HR_ERR_INVALID;
+    if (ctx->cfg.gate_mode == HR_GATE_EXACT) return HR_ERR_INVALID;
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    HIPCHK(hipSetDevice(ctx->cfg.device));
+    hipStream_t st = ctx->stream;
+    const size_t hist_bytes = kEbuBins * sizeof(uint32_t);
+    if (!ctx->hist.ensure(hist_bytes) || !ctx->st_hist.ensure(hist_bytes) || !ctx->gate_parts.ensure(sizeof(GatePart)) ||
+        !ctx->outs.ensure(sizeof(TrackOut)) || !ctx->tracks_d.ensure(sizeof(TrackDesc)) || !ctx->blk_powers.ensure(sizeof(double)) ||
+        !ctx->hop_sums.ensure(sizeof(double)) || !ctx->shard_red.ensure(sizeof(ShardReduced)))
+        return HR_ERR_OOM;
+    const int nb = ctx->cfg.gate_mode == HR_GATE_LOUDNORM ? kLnBins : kEbuBins;
+    launch_reduce_partials(partials_dev, n, nb, ctx->hist.as<uint32_t>(), ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(),
+                           ctx->tracks_d.as<TrackDesc>(), ctx->shard_red.as<ShardReduced>(), st);
+    HIPCHK(hipMemsetAsync(ctx->outs.p, 0, sizeof(TrackOut), st));
+    launch_gate_final(ctx->tracks_d.as<TrackDesc>(), 1, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
+                      ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
+                      ctx->gate_parts.as<GatePart>(), false, ctx->outs.as<TrackOut>(), st);
+    launch_range_stats(ctx->tracks_d.as<TrackDesc>(), 1, nullptr, 0, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(),
+                       ctx->blk_powers.as<double>(), ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->ebu_edges.as<double>(),
+                       ctx->st_hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), true, ctx->outs.as<TrackOut>(), st);
+    HIPCHK(hipGetLastError());
+    TrackOut o{};
+    ShardReduced red{};
+    HIPCHK(hipMemcpyAsync(&o, ctx->outs.p, sizeof o, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(&red, ctx->shard_red.p, sizeof red, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (red.too_large) return HR_ERR_TOO_LARGE;
+    unsigned long long pk[kMaxCh] = {0};
+    for (int c = 0; c < channels; c++) std::memcpy(&pk[c], &red.peak_per_ch[c], sizeof(double));
+    std::memset(out, 0, sizeof *out);
+    fill_result(ctx, o, pk, channels, out, red.range_ok != 0);
+    if (red.redo) return HR_SHARD_AGAIN;  // (out holds lower bounds of the peaks until the redo has run on every rank)
+    ctx->shard_open = false;
+    ctx->shard_device = false;
+    return HR_OK;
+} HR_CATCH_ALL
+
 int hr_shard_pass2(hr_ctx *ctx, const hr_shard_edge *left, hr_shard_partial *partial)
 try {
     if (!ctx || !partial) return HR_ERR_INVALID;
     std::lock_guard<std::mutex> lk(ctx->mu);
-    if (!ctx->shard_open || ctx->shard_pass2_done || !ctx->shard_group) return HR_ERR_INVALID;
+    if (!ctx->shard_open || ctx->shard_device || ctx->shard_pass2_done || !ctx->shard_group) return HR_ERR_INVALID;
     HIPCHK(hipSetDevice(ctx->cfg.device));
     hipStream_t st = ctx->stream;
     Group &g = *ctx->shard_group;
@@ -1694,7 +1834,181 @@ try {
     return HR_OK;
 } HR_CATCH_ALL
 
-// Config 5 inside one process: one context per GPU, the exchange steps on the host (a few KB).
+}  // extern "C"
+
+namespace {
+
+// RCCL, opened at run time: the meter must load (and serve every other entry point) on machines without it, and in a process
+// where PyTorch has already brought its own copy the loader hands back that one (same SONAME) instead of a second runtime.
+struct RcclApi {
+    decltype(&ncclCommInitAll) CommInitAll = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    bool ok = false;
+};
+
+const RcclApi &rccl()
+{
+    static const RcclApi api = [] {
+        RcclApi a;
+        void *h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!h) return a;
+        a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+        a.Send = reinterpret_cast<decltype(a.Send)>(dlsym(h, "ncclSend"));
+        a.Recv = reinterpret_cast<decltype(a.Recv)>(dlsym(h, "ncclRecv"));
+        a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+        a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.CommInitAll && a.CommDestroy && a.AllGather && a.Send && a.Recv && a.GroupStart && a.GroupEnd && a.GetErrorString;
+        return a;
+    }();
+    return api;
+}
+
+// One communicator set per ordered list of distinct devices, kept for the life of the process (creating one costs tens of
+// milliseconds; a stream is analysed in a few).
+std::mutex g_comm_mu;
+std::map<std::vector<int>, std::vector<ncclComm_t>> g_comms;
+
+const std::vector<ncclComm_t> *comms_for(const std::vector<int> &devs)
+{
+    std::lock_guard<std::mutex> lk(g_comm_mu);
+    auto it = g_comms.find(devs);
+    if (it != g_comms.end()) return &it->second;
+    std::vector<ncclComm_t> comms(devs.size());
+    const ncclResult_t rc = rccl().CommInitAll(comms.data(), static_cast<int>(devs.size()), devs.data());
+    if (rc != ncclSuccess) {
+        std::fprintf(stderr, "headroom_hip: ncclCommInitAll failed: %s\n", rccl().GetErrorString(rc));
+        return nullptr;
+    }
+    return &g_comms.emplace(devs, std::move(comms)).first->second;
+}
+
+#define NCCLCHK(expr)                                                                                      \
+    do {                                                                                                   \
+        const ncclResult_t r__ = (expr);                                                                   \
+        if (r__ != ncclSuccess) {                                                                          \
+            std::fprintf(stderr, "headroom_hip: %s failed: %s\n", #expr, rccl().GetErrorString(r__));      \
+            return HR_ERR_HIP;                                                                             \
+        }                                                                                                  \
+    } while (0)
+
+// The device-resident exchange of hr_analyze_stream_sharded (every gating mode but HR_GATE_EXACT): pass 1 leaves each
+// shard's right edge in its context's buffer, the edges move one context to the right, pass 2 leaves the partial images,
+// they are all-gathered, and the first context reduces them in shard order and finishes.  Contexts on DISTINCT devices
+// exchange through RCCL (ncclSend / ncclRecv for the edges, one ncclAllGather for the partials: stream-ordered on each
+// context's stream, over xGMI, no host synchronisation between the phases); contexts that share a device -- the tests and
+// the one-GPU rehearsal: a communicator cannot hold one device twice -- take stream-ordered device copies instead.
+int stream_sharded_device(hr_ctx *const *ctxs, int active, const std::vector<hr_track> &shard, const std::vector<uint64_t> &cut, uint32_t hop,
+                          const std::vector<std::vector<double>> &head, const std::vector<std::vector<double>> &tail, int channels,
+                          hr_result *out)
+{
+    std::vector<int> devs(active);
+    bool distinct = true;
+    for (int r = 0; r < active; r++) {
+        devs[r] = ctxs[r]->cfg.device;
+        for (int q = 0; q < r; q++) distinct &= devs[q] != devs[r];
+    }
+    // HR_SHARD_RCCL=0 keeps the copies; =1 also sends a single shard through a one-rank communicator (the test on a one-GPU box)
+    const char *env = std::getenv("HR_SHARD_RCCL");
+    const bool want = env ? std::atoi(env) != 0 : active > 1;
+    const std::vector<ncclComm_t> *comms = nullptr;
+    if (want && distinct && (active > 1 || env) && rccl().ok) comms = comms_for(devs);
+    for (int r = 0; r < active; r++) {
+        hr_ctx *c = ctxs[r];
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return HR_ERR_HIP;
+        if (!c->shard_edge_buf.ensure(sizeof(hr_shard_edge)) || !c->shard_left_buf.ensure(sizeof(hr_shard_edge)) ||
+            !c->shard_part_buf.ensure(sizeof(hr_shard_partial)) ||
+            !c->shard_gather_buf.ensure(static_cast<size_t>(active) * sizeof(hr_shard_partial)))
+            return HR_ERR_OOM;
+    }
+    std::vector<int> rcs(active, HR_OK);
+    auto on_all = [&](auto fn) {  // one host thread per context: the GPUs work at the same time
+        std::vector<std::thread> th;
+        for (int r = 1; r < active; r++) th.emplace_back([&, r] { rcs[r] = fn(r); });
+        rcs[0] = fn(0);
+        for (auto &t : th) t.join();
+        for (int r = 0; r < active; r++)
+            if (rcs[r]) return rcs[r];
+        return static_cast<int>(HR_OK);
+    };
+    // edges: context r's right edge becomes context r + 1's left edge
+    auto move_edges = [&](int r) -> int {
+        hr_ctx *c = ctxs[r];
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return HR_ERR_HIP;
+        if (comms) {
+            NCCLCHK(rccl().GroupStart());
+            if (r + 1 < active) NCCLCHK(rccl().Send(c->shard_edge_buf.p, sizeof(hr_shard_edge), ncclUint8, r + 1, (*comms)[r], c->stream));
+            if (r > 0) NCCLCHK(rccl().Recv(c->shard_left_buf.p, sizeof(hr_shard_edge), ncclUint8, r - 1, (*comms)[r], c->stream));
+            NCCLCHK(rccl().GroupEnd());
+        } else if (r > 0) {
+            // (the left context's stream has been synchronised by the caller of this phase)
+            HIPCHK(hipMemcpyPeerAsync(c->shard_left_buf.p, c->cfg.device, ctxs[r - 1]->shard_edge_buf.p, ctxs[r - 1]->cfg.device,
+                                      sizeof(hr_shard_edge), c->stream));
+        }
+        return HR_OK;
+    };
+    auto gather = [&](int r) -> int {
+        hr_ctx *c = ctxs[r];
+        if (hipSetDevice(c->cfg.device) != hipSuccess) return HR_ERR_HIP;
+        if (comms) {
+            NCCLCHK(rccl().AllGather(c->shard_part_buf.p, c->shard_gather_buf.p, sizeof(hr_shard_partial), ncclUint8, (*comms)[r], c->stream));
+        } else if (r == 0) {
+            for (int q = 0; q < active; q++)
+                HIPCHK(hipMemcpyPeerAsync(static_cast<char *>(c->shard_gather_buf.p) + static_cast<size_t>(q) * sizeof(hr_shard_partial), c->cfg.device,
+                                          ctxs[q]->shard_part_buf.p, ctxs[q]->cfg.device, sizeof(hr_shard_partial), c->stream));
+        }
+        return HR_OK;
+    };
+    auto sync_all = [&]() -> int {  // (the copy path only: the collectives are ordered on the streams)
+        for (int r = 0; r < active; r++) {
+            if (hipSetDevice(ctxs[r]->cfg.device) != hipSuccess || hipStreamSynchronize(ctxs[r]->stream) != hipSuccess) return HR_ERR_HIP;
+        }
+        return HR_OK;
+    };
+    int rc = on_all([&](int r) {
+        return hr_shard_pass1_device(ctxs[r], &shard[r], r ? tail[r - 1].data() : nullptr, r + 1 < active ? head[r + 1].data() : nullptr,
+                                     r == 0, r + 1 == active, cut[r] / hop, ctxs[r]->shard_edge_buf.p);
+    });
+    if (rc) return rc;
+    if (!comms && (rc = sync_all())) return rc;
+    if ((rc = on_all(move_edges))) return rc;
+    rc = on_all([&](int r) { return hr_shard_pass2_device(ctxs[r], r ? ctxs[r]->shard_left_buf.p : nullptr, ctxs[r]->shard_part_buf.p); });
+    if (rc) return rc;
+    for (int round = 0; round < 2; round++) {
+        if (!comms && (rc = sync_all())) return rc;
+        if ((rc = on_all(gather))) return rc;
+        rc = hr_shard_finish_gathered(ctxs[0], ctxs[0]->shard_gather_buf.p, active, channels, out);
+        if (rc != HR_SHARD_AGAIN) break;
+        // some shard's true-peak screen left work for the exact redo (tones): every context patches its image, then once more
+        if ((rc = on_all([&](int r) { return hr_shard_redo_device(ctxs[r], ctxs[r]->shard_part_buf.p); }))) return rc;
+        rc = HR_ERR_HIP;  // (a second HR_SHARD_AGAIN cannot happen: the redo clears the flag)
+    }
+    // the other contexts' shards are done too
+    for (int r = 1; r < active; r++) {
+        std::lock_guard<std::mutex> lk(ctxs[r]->mu);
+        if (comms && (hipSetDevice(ctxs[r]->cfg.device) != hipSuccess || hipStreamSynchronize(ctxs[r]->stream) != hipSuccess)) return HR_ERR_HIP;
+        ctxs[r]->shard_open = false;
+        ctxs[r]->shard_device = false;
+    }
+    return rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+// Config 5 inside one process: one context per GPU.  HR_GATE_EXACT: the exchange steps on the host (a few KB); the other
+// gating modes: records resident on the devices, RCCL between distinct devices (stream_sharded_device above).
 int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *track, hr_result *out)
 try {
     if (!ctxs || n_ctx < 1 || !track || !out) return HR_ERR_INVALID;
@@ -1734,6 +2048,7 @@ try {
             if (rc) return rc;
         }
     }
+    if (ctxs[0]->cfg.gate_mode != HR_GATE_EXACT) return stream_sharded_device(ctxs, active, shard, cut, hop, head, tail, track->channels, out);
     std::vector<hr_shard_edge> edge(active);
     std::vector<hr_shard_partial> part(active);
     std::vector<int> rcs(active, HR_OK);

@@ -343,6 +343,9 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
     const RateDev &r = rates[t.rate_idx];
     const bool passthru0 = r.tp_passthru0 != 0;  // else (BS.1770 bank) the sample peak bounds nothing and phase 0 is screened
     const KCoef kc = r.k;
+    // (Measured and dropped, round 3: not K-weighting a channel without loudness weight -- the LFE of 5.1 / 7.1.  The waves of
+    // a workgroup step in lock step, so the wave that holds it only waits longer at the barrier, and the wave-uniform branch
+    // around every sample's K-weighting cost all waves 6 %: 355 against 378 audio-hours/s on BASELINE configs[3].)
     const uint32_t hop = it.row_len;  // frames per row: a hop, or a whole fraction of one
     const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
     const int n_rows = static_cast<int>(it.n_rows);  // 0: a padding item (computes on row 0, reports nothing)

@@ -135,6 +135,8 @@ try {
             const uint64_t size = get_be32(ck + 4);
             const size_t body = pos + 8;
             if (!std::memcmp(ck, "COMM", 4)) {
+                // (the probe has checked the COMM chunk it used; a file may carry a second, truncated one)
+                if (body + 18 > file.size()) return HR_ERR_FORMAT;
                 out.insert(out.end(), {'C', 'O', 'M', 'M'});
                 put_be32(out, 18);
                 put_be16(out, track.channels);

@@ -94,6 +94,23 @@ struct FpItem { uint32_t src, ch, first_hop, n_rows; };  // one wave: hops first
 void launch_first_pass_rows(const FpSrc *srcs, const RateDev *rates, const FpItem *items, uint32_t n_items, HopRec *recs,
                             unsigned long long *peaks, hipStream_t st);
 
+// hr_kernels_shard.hip: the exchange records of a time-sharded stream on the device, in the layouts of headroom_hip.h
+// (edge / partial / partials point at hr_shard_edge / hr_shard_partial images in device memory)
+struct ShardReduced {  // what the host still needs of the reduced partials
+    double peak_per_ch[kMaxCh];
+    int32_t range_ok;   // minimum over the shards
+    int32_t redo;       // some shard's image carries peaks that its exact redo has not confirmed yet
+    int32_t too_large;  // a reduced histogram count passed 32 bits
+    int32_t pad_;
+};
+void launch_pack_edge(const TrackDesc *tracks, const HopRec *recs, const double *hop_sums, bool is_first, void *edge, hipStream_t st);
+void launch_unpack_edge(TrackDesc *tracks, HopRec *recs, double *hop_sums, const void *left_edge, hipStream_t st);
+void launch_pack_partial(const TrackDesc *tracks, const uint32_t *hist, const uint32_t *st_hist, const GatePart *parts, const TrackOut *outs,
+                         const unsigned long long *peaks, const unsigned *overflow, const void *left_edge, int nb, void *partial, hipStream_t st);
+void launch_patch_partial_peaks(const TrackDesc *tracks, const unsigned long long *peaks, void *partial, hipStream_t st);
+void launch_reduce_partials(const void *partials, int n, int nb, uint32_t *hist, uint32_t *st_hist, GatePart *gp, TrackDesc *tracks,
+                            ShardReduced *red, hipStream_t st);
+
 // hr_gain.hip: interleaved PCM of format fmt times vol (f32) -> packed s24 (dst dword aligned); *clipped += samples
 // that saturated
 void launch_apply_gain(int fmt, bool big_endian, const void *src, void *dst, uint64_t n_samples, float vol,

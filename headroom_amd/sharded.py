@@ -7,7 +7,10 @@ Two ways the path shards:
   does across threads, src/cli.rs:403-435);
 * one long stream cut in time -- `cut_stream` picks hop-aligned cuts, `analyze_stream_shard` runs
   hr_shard_head / pass1 / pass2 / finish with a neighbour exchange of `hr_shard_edge` and an all-reduce
-  of `hr_shard_partial` in between.
+  of `hr_shard_partial` in between (records in host structs; serves every gating mode);
+  `analyze_stream_shard_device` (round 3) is the same exchange with the records resident on the GPUs:
+  one neighbour send / receive of the edge and ONE all-gather of the partial, both on device tensors, the
+  halos handed in with the shard, one synchronisation at the end.
 
 The backend is whatever the process group was created with: "nccl" (RCCL over xGMI) on the GPUs,
 "gloo" in the CPU tests.  Payloads are a few KB; both steps are latency-bound.
@@ -16,7 +19,7 @@ import ctypes as C
 
 import numpy as np
 
-from . import GATE_EXACT, HrShardEdge, HrShardPartial, MAX_CH
+from . import GATE_EXACT, SHARD_AGAIN, HrShardEdge, HrShardPartial, MAX_CH
 
 MIN_SHARD_HOPS = 6  # hr_shard_pass1: a shard hands the records of its last 6 hops to the right
 
@@ -163,6 +166,110 @@ def analyze_stream_shard(dist, meter, shard_spec, rank, active, channels, first_
     out = meter.shard_finish(red, channels)
     lap("finish")
     return out
+
+
+class ShardBuffers:
+    """The device buffers of analyze_stream_shard_device, allocated once per rank: this shard's right edge, the left
+    neighbour's edge, this shard's partial, and the gathered partials of all ranks (images of the C structs)."""
+
+    def __init__(self, world, device):
+        import torch
+        self.edge = torch.zeros(C.sizeof(HrShardEdge), dtype=torch.uint8, device=device)
+        self.left = torch.zeros(C.sizeof(HrShardEdge), dtype=torch.uint8, device=device)
+        self.part = torch.zeros(C.sizeof(HrShardPartial), dtype=torch.uint8, device=device)
+        self.gathered = torch.zeros(world * C.sizeof(HrShardPartial), dtype=torch.uint8, device=device)
+        idle = HrShardPartial()
+        idle.range_ok = 1  # a rank that sits the passes out does not veto the range statistics
+        self.idle = torch.from_numpy(_as_bytes(idle).copy()).to(device)
+
+
+def shard_halos(dist, meter, shard_spec, rank, active):
+    """(left_tail, right_head) of this rank's shard: the 16 frames either side of it, as hr_shard_pass1 takes them.  Whoever
+    cuts the stream can hand them over with the shard; ranks that hold only their own shard fetch them from the
+    neighbours once, here (not part of the per-call exchange)."""
+    if shard_spec is None or rank >= active:
+        return None, None
+    return _exchange_halos(dist, meter, shard_spec, meter.shard_head(shard_spec), rank, active)
+
+
+def analyze_stream_shard_device(dist, meter, shard_spec, rank, active, channels, first_hop=0, halos=None, bufs=None,
+                                shared_stream=False, timings=None):
+    """One rank's part of a time-sharded stream with the exchange records resident on the device (hr_shard_pass1_device /
+    hr_shard_pass2_device / hr_shard_finish_gathered; every gating mode but GATE_EXACT).  Per call: one neighbour
+    send / receive of the edge, one all-gather of the partial, one synchronisation (inside the finish).  Over "nccl" the
+    tensors never leave the GPUs; over "gloo" (CPU tests, the one-device rehearsal) each of the two steps is staged through
+    host memory.  `halos` = (left_tail, right_head) from shard_halos() or from whoever cut the stream; None: fetched here.
+    shared_stream: the meter was created on torch's current stream (Meter(stream=torch.cuda.current_stream().cuda_stream)),
+    so the collectives and the library's kernels are ordered on it and nothing waits on the host between the phases;
+    otherwise the two are ordered through synchronisations.  Every rank of the group must call this."""
+    import time
+
+    import torch
+    t = [time.perf_counter()]
+
+    def lap(name):
+        t.append(time.perf_counter())
+        if timings is not None:
+            timings[name] = timings.get(name, 0.0) + (t[-1] - t[-2])
+
+    world = dist.get_world_size()
+    on_gpu = dist.get_backend() == "nccl"
+    if bufs is None:
+        bufs = ShardBuffers(world, torch.device("cuda", torch.cuda.current_device()))
+    mine = shard_spec is not None and rank < active
+
+    def order():  # the library's stream and torch's: the same one, or brought together on the host
+        if bufs.edge.is_cuda and not (shared_stream and on_gpu):
+            torch.cuda.synchronize()
+
+    if mine:
+        if halos is None:
+            halos = shard_halos(dist, meter, shard_spec, rank, active)
+            lap("halo_exchange")
+        meter.shard_pass1_device(shard_spec, halos[0], halos[1], first_hop, bufs.edge.data_ptr())
+        order()  # (where the streams are brought together on the host, the kernels' time shows up in this phase)
+        lap("pass1")
+        ops = []
+        if on_gpu:
+            if rank + 1 < active:
+                ops.append(dist.P2POp(dist.isend, bufs.edge, rank + 1))
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, bufs.left, rank - 1))
+        else:
+            host_left = torch.empty(C.sizeof(HrShardEdge), dtype=torch.uint8) if rank > 0 else None
+            if rank + 1 < active:
+                ops.append(dist.P2POp(dist.isend, bufs.edge.cpu(), rank + 1))
+            if rank > 0:
+                ops.append(dist.P2POp(dist.irecv, host_left, rank - 1))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()
+        if not on_gpu and rank > 0:
+            bufs.left.copy_(host_left)
+        order()
+        lap("edge_exchange")
+        meter.shard_pass2_device(bufs.left.data_ptr() if rank > 0 else None, bufs.part.data_ptr())
+        order()
+        lap("pass2")
+    else:
+        bufs.part.copy_(bufs.idle)
+    while True:
+        if on_gpu:
+            dist.all_gather_into_tensor(bufs.gathered, bufs.part)
+        else:
+            host = torch.empty(world * C.sizeof(HrShardPartial), dtype=torch.uint8)
+            dist.all_gather_into_tensor(host, bufs.part.cpu())
+            bufs.gathered.copy_(host)
+        order()
+        lap("all_gather")
+        rc, out = meter.shard_finish_gathered(bufs.gathered.data_ptr(), world, channels)
+        lap("finish")
+        if rc != SHARD_AGAIN:
+            return out
+        if mine:  # some shard's exact true-peak redo was pending: every rank patches its image, then once more
+            meter.shard_redo_device(bufs.part.data_ptr())
+        order()
+        lap("redo")
 
 
 def _exchange_halos(dist, meter, shard_spec, head, rank, active):

@@ -223,9 +223,35 @@ int hr_shard_pass3(hr_ctx *ctx, const hr_shard_partial *reduced, hr_shard_partia
 /* Gating from the all-reduced partial. */
 int hr_shard_finish(hr_ctx *ctx, const hr_shard_partial *reduced, int channels, hr_result *out);
 
-/* The same inside ONE process: n_ctx contexts (one per GPU; same modes in all of them) each take one time shard of `track`, the exchange steps above run on the host.  Host PCM, or
+/* The same exchange with the records RESIDENT ON THE DEVICE (round 3; every gating mode but HR_GATE_EXACT, whose two dependent
+ * reductions stay with the entry points above: HR_ERR_INVALID here).  The edge and the partial are written into / read from
+ * device buffers of the caller -- images of hr_shard_edge / hr_shard_partial, sizeof() bytes each -- so that the caller's
+ * communicator moves them GPU to GPU with no host round trip: ncclSend / ncclRecv of the edge to the right neighbour, ONE
+ * ncclAllGather of the partial (n images back to back), then hr_shard_finish_gathered, which reduces the images in rank
+ * order on the device (reproducible sums) and finishes.  A rank that sits the passes out contributes an all-zero image with
+ * range_ok = 1.  hr_shard_pass1_device / hr_shard_pass2_device / hr_shard_redo_device only QUEUE work on the context's stream
+ * (hr_config.stream, or the context's own) and return without waiting for it: issue the collectives on that stream, or
+ * order yours behind it.  hr_shard_finish_gathered synchronises the stream once and returns
+ *   HR_OK           out is final;
+ *   HR_SHARD_AGAIN  some shard's true-peak screen left work for its exact redo (sustained tones; the image's `reserved`
+ *                   says so, which is how every rank learns it from the same gathered bytes): every rank calls
+ *                   hr_shard_redo_device on its partial buffer, the partials are gathered again, and
+ *                   hr_shard_finish_gathered is called again -- it returns HR_OK then.
+ * The shard's PCM must stay valid until the final hr_shard_finish_gathered.  INTEGRATION.md section 4 shows the sequence with
+ * ncclAllGather; headroom_amd/sharded.py analyze_stream_shard_device runs it over torch.distributed. */
+#define HR_SHARD_AGAIN 1
+int hr_shard_pass1_device(hr_ctx *ctx, const hr_track *shard, const double *left_tail, const double *right_head,
+                          int is_first, int is_last, uint64_t first_hop, void *edge_dev_out);
+int hr_shard_pass2_device(hr_ctx *ctx, const void *left_edge_dev, void *partial_dev_out);
+int hr_shard_redo_device(hr_ctx *ctx, void *partial_dev_inout);
+int hr_shard_finish_gathered(hr_ctx *ctx, const void *partials_dev, int n, int channels, hr_result *out);
+
+/* The same inside ONE process: n_ctx contexts (one per GPU; same modes in all of them) each take one time shard of `track`.  Host PCM, or
  * device PCM when every context sits on the GPU that holds it.  Streams too short to cut (fewer than six
- * hops per shard) use fewer contexts.  No counterpart in the reference. */
+ * hops per shard) use fewer contexts.  Contexts on distinct GPUs exchange their records through RCCL inside the library
+ * (ncclSend / ncclRecv of the edges, one ncclAllGather of the gating partials, over xGMI; librccl is opened at run time);
+ * contexts that share a GPU, and HR_GATE_EXACT, take device copies / the host records instead.  No counterpart in the
+ * reference. */
 int hr_analyze_stream_sharded(hr_ctx *const *ctxs, int n_ctx, const hr_track *track, hr_result *out);
 
 /* Deterministic synthetic PCM written straight into device memory (bench / tests):

@@ -22,6 +22,7 @@ pub mod sys {
     pub const HR_MAX_CH: usize = 8;
     pub const HR_MAX_SAMPLE_RATE: u32 = 768_000;
     pub const HR_NOALLOC_MAX_HOP_CHANNELS: u32 = 65_536;
+    pub const HR_SHARD_AGAIN: c_int = 1;
 
     pub const HR_OK: c_int = 0;
     pub const HR_ERR_INVALID: c_int = -1;
@@ -191,6 +192,14 @@ pub mod sys {
         pub fn hr_shard_pass2(ctx: *mut hr_ctx, left_edge: *const hr_shard_edge, partial_out: *mut hr_shard_partial) -> c_int;
         pub fn hr_shard_pass3(ctx: *mut hr_ctx, reduced: *const hr_shard_partial, partial_out: *mut hr_shard_partial) -> c_int;
         pub fn hr_shard_finish(ctx: *mut hr_ctx, reduced: *const hr_shard_partial, channels: c_int, out: *mut hr_result) -> c_int;
+        // the same exchange with the records resident on the device (images of hr_shard_edge / hr_shard_partial in
+        // device memory of the caller: what ncclSend / ncclRecv / ncclAllGather move); HR_SHARD_AGAIN from the finish asks
+        // every rank for hr_shard_redo_device and one more gather
+        pub fn hr_shard_pass1_device(ctx: *mut hr_ctx, shard: *const hr_track, left_tail: *const f64, right_head: *const f64,
+                                     is_first: c_int, is_last: c_int, first_hop: u64, edge_dev_out: *mut c_void) -> c_int;
+        pub fn hr_shard_pass2_device(ctx: *mut hr_ctx, left_edge_dev: *const c_void, partial_dev_out: *mut c_void) -> c_int;
+        pub fn hr_shard_redo_device(ctx: *mut hr_ctx, partial_dev_inout: *mut c_void) -> c_int;
+        pub fn hr_shard_finish_gathered(ctx: *mut hr_ctx, partials_dev: *const c_void, n: c_int, channels: c_int, out: *mut hr_result) -> c_int;
         pub fn hr_analyze_stream_sharded(ctxs: *const *mut hr_ctx, n_ctx: c_int, track: *const hr_track, out: *mut hr_result) -> c_int;
         pub fn hr_synth_fill(ctx: *mut hr_ctx, device_pcm: *mut c_void, seed: u64, sample_rate: u32, channels: u32, frames: u64) -> c_int;
         pub fn hr_last_timing(ctx: *mut hr_ctx, total_ms: *mut f32, main_kernel_ms: *mut f32) -> c_int;

@@ -6,6 +6,7 @@ mode "cpu": the N>1 host logic of headroom_amd.sharded without a GPU -- track pa
 mode "gpu": the same drivers over the real C ABI, every rank with its own context on cuda:0, checked
             against the unsharded result and the oracle.
 """
+import ctypes as C
 import os
 import sys
 
@@ -77,6 +78,28 @@ class RecordingMeter:
 
     def shard_finish(self, red, channels):
         return red
+
+
+    # ---- the device-resident protocol: the records are written into / read from the caller's buffers (host memory here) ----
+    def shard_pass1_device(self, spec, left_tail, right_head, first_hop, edge_ptr):
+        e = self.shard_pass1(spec, left_tail, right_head, first_hop)
+        C.memmove(edge_ptr, C.addressof(e), C.sizeof(e))
+
+    def shard_pass2_device(self, left_edge_ptr, partial_ptr):
+        left = hr.HrShardEdge.from_address(left_edge_ptr) if left_edge_ptr else None
+        p = self.shard_pass2(left)
+        C.memmove(partial_ptr, C.addressof(p), C.sizeof(p))
+
+    def shard_finish_gathered(self, gathered_ptr, n, channels):
+        parts = (hr.HrShardPartial * n).from_address(gathered_ptr)
+        self.seen["finish_calls"] = self.seen.get("finish_calls", 0) + 1
+        if any(p.reserved for p in parts):
+            return hr.SHARD_AGAIN, None
+        return hr.OK, [hr.HrShardPartial.from_buffer_copy(p) for p in parts]
+
+    def shard_redo_device(self, partial_ptr):
+        hr.HrShardPartial.from_address(partial_ptr).reserved = 0
+        self.seen["redo"] = True
 
 
 class FakeSpec:
@@ -151,6 +174,34 @@ def mode_cpu(rank, world):
     assert mx.seen["reduced_for_pass3"] == (sum(0.5 + r for r in range(world)), sum(10 + r for r in range(world)))
     assert redx.sum_gated == sum(0.125 * (r + 1) for r in range(world)) and redx.n_gated == sum(3 + r for r in range(world))
 
+    # --- the same flow with the records in buffers of the caller (the device-resident protocol, in host memory here): the
+    # edge reaches the right neighbour byte for byte, every rank ends up with every rank's partial in rank order, an idle
+    # rank contributes the neutral image, and a pending redo on ONE rank sends every rank round once more
+    bufs = sharded.ShardBuffers(world, torch.device("cpu"))
+    md = RecordingMeter(rank)
+    halos = sharded.shard_halos(dist, md, spec, rank, world)
+    parts = sharded.analyze_stream_shard_device(dist, md, spec, rank, world, 2, first_hop=cuts[rank] // 4800, halos=halos, bufs=bufs)
+    assert len(parts) == world and [p.n_blocks for p in parts] == [100 + r for r in range(world)]
+    assert [p.hist[r] for r, p in enumerate(parts)] == [1 + r for r in range(world)] and md.seen["finish_calls"] == 1
+    if rank > 0:
+        le = md.seen["left_edge"]
+        assert le.n_hops == (cuts[rank] - cuts[rank - 1]) // 4800 and np.ctypeslib.as_array(le.rec)[5, 7, 8] == 1000.0 * (rank - 1) + 431
+        assert np.array_equal(md.seen["left_tail"][:, :2], pcm[cuts[rank] - 16:cuts[rank]])
+    else:
+        assert md.seen["left_edge"] is None and md.seen["left_tail"] is None
+
+    class Redo(RecordingMeter):
+        def shard_pass2(self, left_edge):
+            p = super().shard_pass2(left_edge)
+            p.reserved = 1 if self.rank == world - 1 else 0
+            return p
+    mr = Redo(rank)
+    parts = sharded.analyze_stream_shard_device(dist, mr, spec, rank, world, 2, halos=halos, bufs=bufs)
+    assert mr.seen["finish_calls"] == 2 and mr.seen.get("redo") and all(p.reserved == 0 for p in parts)
+    mi = RecordingMeter(rank)
+    parts = sharded.analyze_stream_shard_device(dist, mi, FakeSpec(pcm[:4800 * 7]) if rank == 0 else None, rank, 1, 2, halos=(None, None), bufs=bufs)
+    assert parts[0].n_blocks == 100 and all(p.n_blocks == 0 and p.range_ok == 1 for p in parts[1:]) and (rank == 0) == ("left_edge" in mi.seen)
+
     # --- a rank with an empty shard sits the passes out but joins the reduction --------------------
     m2 = RecordingMeter(rank)
     red2 = sharded.analyze_stream_shard(dist, m2, FakeSpec(pcm[:4800 * 7]) if rank == 0 else None, rank, 1, 2)
@@ -190,6 +241,35 @@ def mode_gpu(rank, world):
             assert abs(got_x["integrated_lufs"] - whole_x["integrated_lufs"]) < 1e-9
             assert abs(got_x["integrated_lufs"] - ref_x["integrated_lufs"]) < 1e-6
             assert got_x["peak_per_ch"] == ref_x["peak_per_ch"]
+        # the exchange with the records resident on the device (hr_shard_pass1_device ...): one edge send / receive, one
+        # all-gather, staged through the host here because the group is gloo; twice on the same buffers, then a stream of
+        # tones, whose candidate lists overflow: the finish answers SHARD_AGAIN and every rank runs its exact redo
+        bufs = sharded.ShardBuffers(world, torch.device("cuda", 0))
+        halos = sharded.shard_halos(dist, m, spec, rank, world)
+        for _ in range(2):
+            phases = {}
+            got_v = sharded.analyze_stream_shard_device(dist, m, spec, rank, world, 2, first_hop=cuts[rank] // 4800, halos=halos, bufs=bufs,
+                                                        timings=phases)
+            assert all(got_v[k] == got[k] or (got_v[k] != got_v[k] and got[k] != got[k]) for k in got), (got_v, got)
+            assert "halo_exchange" not in phases and "redo" not in phases
+        t = np.arange(pcm.shape[0]) / fs
+        tones = np.stack([0.999 * np.sin(2 * np.pi * 997.0 * t), 0.5 * np.sin(2 * np.pi * 3001.0 * t + 1.0)], axis=1).astype(np.float32)
+        tspec = hr.TrackSpec(tones[cuts[rank]:cuts[rank + 1]].copy(), fs)
+        phases = {}
+        got_t = sharded.analyze_stream_shard_device(dist, m, tspec, rank, world, 2, first_hop=cuts[rank] // 4800, bufs=bufs, timings=phases)
+        ref_t = oracle.measure(tones, fs)
+        assert "redo" in phases and "halo_exchange" in phases
+        assert got_t["peak_per_ch"] == ref_t["peak_per_ch"], (got_t, ref_t)
+        assert got_t["n_gated"] == ref_t["n_gated"] and abs(got_t["integrated_lufs"] - ref_t["integrated_lufs"]) < 1e-6
+        # a stream too short to give every rank a shard: the idle ranks contribute the neutral image
+        short = pcm[: 4800 * 7 + 33]
+        cs = sharded.cut_stream(short.shape[0], fs, world)
+        act = sharded.active_shards(cs)
+        sspec = hr.TrackSpec(short[cs[rank]:cs[rank + 1]].copy(), fs) if cs[rank + 1] > cs[rank] else None
+        got_s = sharded.analyze_stream_shard_device(dist, m, sspec, rank, act, 2, first_hop=cs[rank] // 4800, bufs=bufs)
+        ref_s = oracle.measure(short, fs)
+        assert act == 1 and got_s["peak_per_ch"] == ref_s["peak_per_ch"] and got_s["n_blocks"] == ref_s["n_blocks"]
+        assert abs(got_s["integrated_lufs"] - ref_s["integrated_lufs"]) < 1e-6
         # the same with the shard resident in HBM (device pointers, offset view for the tail)
         dev = torch.from_numpy(pcm[cuts[rank]:cuts[rank + 1]].copy()).cuda()
         got_d = sharded.analyze_stream_shard(dist, m, hr.TrackSpec(dev, fs), rank, world, 2, first_hop=cuts[rank] // 4800)

@@ -448,6 +448,26 @@ def test_analyze_stream_sharded_in_process(oracle, meters, gate):
             m.close()
 
 
+def test_in_process_shards_through_a_one_rank_rccl_communicator(oracle, monkeypatch):
+    """hr_analyze_stream_sharded moves its records with RCCL when its contexts sit on distinct GPUs.  A one-GPU box can
+    show only the smallest communicator: HR_SHARD_RCCL=1 sends a single shard's partial through ncclAllGather on a one-rank
+    communicator (librccl opened at run time, the collective ordered on the context's stream, the gathered image
+    reduced and finished on the device)."""
+    fs = 48000
+    pcm = signals.seeded_noise(4711, 4800 * 31 + 99, 2, -17.0)
+    pcm[: fs] *= 0.01
+    ref = oracle.measure(pcm, fs)
+    monkeypatch.setenv("HR_SHARD_RCCL", "1")
+    with hr.Meter(device=0) as m:
+        got = hr.analyze_stream_sharded([m], hr.TrackSpec(pcm, fs))
+        whole = m.analyze(pcm, fs)
+    assert got["peak_per_ch"] == whole["peak_per_ch"] == ref["peak_per_ch"]
+    assert got["n_blocks"] == ref["n_blocks"] and got["n_gated"] == ref["n_gated"]
+    assert abs(got["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6 and abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
+    for k in ("loudness_range_lu", "max_momentary_lufs", "max_shortterm_lufs"):
+        assert abs(got[k] - whole[k]) < 1e-9
+
+
 @pytest.mark.parametrize("fs", [44100, 48000])
 def test_integer_stereo_tracks_take_the_fused_kernel(oracle, meters, fs):
     """s24 stereo is widened to f32 on the device (exactly), s16 stereo read directly, and measured by the fused kernel: same numbers
