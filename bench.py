@@ -434,7 +434,7 @@ def run_config5(args, meter, dev, local, rank=0, world=1, rehearsal=False):
 
             def one_call(timings=None):
                 return sharded.analyze_stream_shard_device(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10), halos=halos,
-                                                           bufs=bufs, shared_stream=not rehearsal, timings=timings)
+                                                           bufs=bufs, shared_stream=not rehearsal, timings=timings, align_phases=rehearsal)
         else:
             def one_call(timings=None):
                 return sharded.analyze_stream_shard(dist, meter, spec, rank, active, ch, first_hop=cuts[rank] // (fs // 10), timings=timings)

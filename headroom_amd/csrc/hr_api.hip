@@ -114,6 +114,7 @@ struct hr_ctx {
     DevBuf rates_d, ebu_energy, ebu_edges, ln_energy, ln_bounds, unit_tap;
 
     // workspace (grow-only)
+    DevBuf stage_b;  // the second staging buffer (hr_analyze_batch alternates between `stage` and this one)
     DevBuf widened, resampled, parents_d, counters, gate_items, gate_parts, st_hist, tracks_d, items_d, comb_items_d, fitems_d, cands, cand_cnt, tpb, overflow, ovf_items, recs, hop_sums, blk_powers, hist, outs, peaks, stage, halos, fp_src_d, fp_items_d;
 
     // host copies of what is in flight on the stream (pageable sources must outlive the async copies)
@@ -145,6 +146,9 @@ struct hr_ctx {
     // latency-bound and tiny: they run beside the fused kernel on a second stream
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // staging copies of the next launch group run on a stream of their own, into the other of two staging buffers
+    hipStream_t copy = nullptr;
+    hipEvent_t ev_staged[2] = {nullptr, nullptr};
     float last_total_ms = 0, last_main_ms = 0;
 
     size_t comb_n = 0;  // combine work items of the last run_measure (comb_items_d)
@@ -164,7 +168,7 @@ struct hr_ctx {
     {
         return {&widened, &resampled, &parents_d, &counters, &gate_items, &gate_parts, &st_hist, &tracks_d, &items_d, &comb_items_d, &fitems_d,
                 &cands, &cand_cnt, &tpb, &overflow, &ovf_items, &recs, &hop_sums, &blk_powers, &hist, &outs, &peaks, &stage, &halos, &fp_src_d, &fp_items_d,
-                &shard_red};
+                &shard_red, &stage_b};
     }
 };
 
@@ -1073,71 +1077,124 @@ void track_peaks(const Group &g, const std::vector<unsigned long long> &pk, int 
         out[c] = d.role == 1 ? pk[(d.first_plane + c / 2) * kMaxCh + (c & 1)] : pk[static_cast<size_t>(di) * kMaxCh + c];
 }
 
-// Stages the host-resident tracks of [begin, end) and measures the group.
-int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t> &idx, hr_result *out)
+// One launch group of hr_analyze_batch in three phases, so that the staging copies of the NEXT group run beside the kernels of
+// this one (pinned H2D on a copy stream, two staging buffers):
+//   group_stage   the group's host-resident (and misaligned device) tracks into staging buffer `half`, on the copy stream
+//   group_launch  descriptors, plane splits, K-weighting + true peak + gating, and the copies of the results, on the main stream
+//                 (which first waits for the staging copies)
+//   group_finish  the one synchronisation, the exact redo where the screen asked for it, the results
+// The workspace behind a launch is the context's: one group is launched and finished before the next is launched; only the
+// staging of the next one overlaps.
+struct GroupJob {
+    std::vector<size_t> idx;   // the group's tracks (indices into the caller's array)
+    std::vector<size_t> off;   // per track: offset in the staging buffer
+    size_t stage_need = 0;
+    int half = 0;
+    Group g;
+    std::vector<int> desc_of;
+    std::vector<TrackOut> outs;
+    std::vector<unsigned long long> pk;
+};
+
+DevBuf &stage_buf(hr_ctx *ctx, int half) { return half ? ctx->stage_b : ctx->stage; }
+
+int group_stage(hr_ctx *ctx, const hr_track *tracks, GroupJob &job)
+{
+    job.off.assign(job.idx.size(), 0);
+    job.stage_need = 0;
+    for (size_t k = 0; k < job.idx.size(); k++) {
+        const hr_track &t = tracks[job.idx[k]];
+        if (on_device(ctx, t)) continue;
+        job.off[k] = job.stage_need;
+        job.stage_need += (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
+    }
+    if (!job.stage_need) return HR_OK;
+    DevBuf &sb = stage_buf(ctx, job.half);
+    if (!sb.ensure(job.stage_need)) return HR_ERR_OOM;
+    hipStream_t cs = ctx->copy ? ctx->copy : ctx->stream;
+    for (size_t k = 0; k < job.idx.size(); k++) {
+        const hr_track &t = tracks[job.idx[k]];
+        if (on_device(ctx, t)) continue;
+        const size_t bytes = t.frames * t.channels * fmt_bytes(t.fmt);
+        if (bytes)
+            HIPCHK(hipMemcpyAsync(static_cast<char *>(sb.p) + job.off[k], t.pcm, bytes,
+                                  (t.flags & HR_TRACK_DEVICE_PCM) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, cs));
+    }
+    if (cs != ctx->stream) HIPCHK(hipEventRecord(ctx->ev_staged[job.half], cs));
+    return HR_OK;
+}
+
+int group_launch(hr_ctx *ctx, const hr_track *tracks, GroupJob &job)
 {
     hipStream_t st = ctx->stream;
-    Group g;
-    // staging layout
-    size_t stage_need = 0;
-    std::vector<size_t> off(idx.size(), 0);
-    for (size_t k = 0; k < idx.size(); k++) {
-        const hr_track &t = tracks[idx[k]];
-        if (on_device(ctx, t)) continue;
-        off[k] = stage_need;
-        stage_need += (t.frames * t.channels * fmt_bytes(t.fmt) + 255) / 256 * 256;
-    }
-    if (stage_need && !ctx->stage.ensure(stage_need)) return HR_ERR_OOM;
+    const std::vector<size_t> &idx = job.idx;
+    if (job.stage_need && ctx->copy) HIPCHK(hipStreamWaitEvent(st, ctx->ev_staged[job.half], 0));
+    DevBuf &sb = stage_buf(ctx, job.half);
     size_t widen_need = 0;
     std::vector<size_t> woff(idx.size(), 0);
     std::vector<uint8_t> sp(idx.size(), 0);
     for (size_t k = 0; k < idx.size(); k++)
         if ((sp[k] = splits(ctx, tracks[idx[k]]))) { woff[k] = widen_need; widen_need += split_bytes(tracks[idx[k]]); }
     if (widen_need && !ctx->widened.ensure(widen_need)) return HR_ERR_OOM;
-    std::vector<int> desc_of(idx.size(), 0);
+    job.desc_of.assign(idx.size(), 0);
     for (size_t k = 0; k < idx.size(); k++) {
         const hr_track &t = tracks[idx[k]];
-        const void *dev = t.pcm;
-        if (!on_device(ctx, t)) {
-            dev = static_cast<char *>(ctx->stage.p) + off[k];
-            const size_t bytes = t.frames * t.channels * fmt_bytes(t.fmt);
-            if (bytes)
-                HIPCHK(hipMemcpyAsync(const_cast<void *>(dev), t.pcm, bytes,
-                                      (t.flags & HR_TRACK_DEVICE_PCM) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
-        }
-        desc_of[k] = add_track(ctx, g, t, dev, reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]), sp[k] != 0);
-        if (desc_of[k] < 0) return desc_of[k];
+        const void *dev = on_device(ctx, t) ? t.pcm : static_cast<char *>(sb.p) + job.off[k];
+        job.desc_of[k] = add_track(ctx, job.g, t, dev, reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]), sp[k] != 0);
+        if (job.desc_of[k] < 0) return job.desc_of[k];
     }
-    int rc = run_measure(ctx, g, true);
+    int rc = run_measure(ctx, job.g, true);
     if (rc) return rc;
-    rc = run_gating(ctx, g, true);
+    rc = run_gating(ctx, job.g, true);
     if (rc) return rc;
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     // the screen's overflow flags come back with the results: one synchronisation in the common case (no flag set)
-    rc = overflow_flags_fetch(ctx, g);
+    rc = overflow_flags_fetch(ctx, job.g);
     if (rc) return rc;
-    const size_t nt = g.descs.size();
-    std::vector<TrackOut> outs(nt);
-    std::vector<unsigned long long> pk(nt * kMaxCh);
-    HIPCHK(hipMemcpyAsync(outs.data(), ctx->outs.p, nt * sizeof(TrackOut), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    const size_t nt = job.g.descs.size();
+    job.outs.resize(nt);
+    job.pk.resize(nt * kMaxCh);
+    HIPCHK(hipMemcpyAsync(job.outs.data(), ctx->outs.p, nt * sizeof(TrackOut), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(job.pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    return HR_OK;
+}
+
+int group_finish(hr_ctx *ctx, const hr_track *tracks, GroupJob &job, hr_result *out)
+{
+    hipStream_t st = ctx->stream;
+    const size_t nt = job.g.descs.size();
     HIPCHK(hipStreamSynchronize(st));
     bool relaunched = false;
-    rc = overflow_redo(ctx, g, &relaunched);
+    const int rc = overflow_redo(ctx, job.g, &relaunched);
     if (rc) return rc;
     if (relaunched) {
-        HIPCHK(hipMemcpyAsync(pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(job.pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
     }
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]) == hipSuccess) ctx->last_total_ms += ms;
     if (hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]) == hipSuccess) ctx->last_main_ms += ms;
-    for (size_t k = 0; k < idx.size(); k++) {
+    for (size_t k = 0; k < job.idx.size(); k++) {
         unsigned long long tpk[kMaxCh];
-        track_peaks(g, pk, desc_of[k], tpk);
-        fill_result(ctx, outs[desc_of[k]], tpk, tracks[idx[k]].channels, &out[idx[k]]);
+        track_peaks(job.g, job.pk, job.desc_of[k], tpk);
+        fill_result(ctx, job.outs[job.desc_of[k]], tpk, tracks[job.idx[k]].channels, &out[job.idx[k]]);
     }
     return HR_OK;
+}
+
+// one group, start to end (callers with a single group: the no-alloc entry point, the loudnorm first pass)
+int analyze_group(hr_ctx *ctx, const hr_track *tracks, const std::vector<size_t> &idx, hr_result *out)
+{
+    GroupJob job;
+    job.idx = idx;
+    int rc = group_stage(ctx, tracks, job);
+    if (!rc) rc = group_launch(ctx, tracks, job);
+    if (!rc) rc = group_finish(ctx, tracks, job, out);
+    if (rc) {  // (whatever was queued must not outlive the job's host buffers)
+        (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->copy) (void)hipStreamSynchronize(ctx->copy);
+    }
+    return rc;
 }
 
 }  // namespace
@@ -1189,7 +1246,10 @@ try {
         if (hipEventCreate(&e) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
     if (hipStreamCreateWithFlags(&ctx->side, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->copy, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_staged[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_staged[1], hipEventDisableTiming) != hipSuccess) { hr_destroy(ctx); return HR_ERR_HIP; }
     int rc = upload(ctx->ebu_energy, ebur128_bin_energy().data(), kEbuBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ebu_edges, ebur128_bin_edges().data(), 3 * kEbuBins * sizeof(double), ctx->stream);
     if (!rc) rc = upload(ctx->ln_energy, loudnorm_bin_energy().data(), kLnBins * sizeof(double), ctx->stream);
@@ -1211,12 +1271,14 @@ void hr_destroy(hr_ctx *ctx)
     for (DevBuf *b : {&ctx->rates_d, &ctx->ebu_energy, &ctx->ebu_edges, &ctx->ln_energy, &ctx->ln_bounds, &ctx->unit_tap, &ctx->tracks_d,
                       &ctx->widened, &ctx->resampled, &ctx->parents_d, &ctx->counters, &ctx->gate_items, &ctx->gate_parts, &ctx->st_hist, &ctx->items_d, &ctx->comb_items_d, &ctx->fitems_d, &ctx->cands, &ctx->cand_cnt, &ctx->tpb, &ctx->overflow, &ctx->ovf_items, &ctx->recs, &ctx->hop_sums, &ctx->blk_powers, &ctx->hist, &ctx->outs, &ctx->peaks,
                       &ctx->stage, &ctx->halos, &ctx->fp_src_d, &ctx->fp_items_d, &ctx->shard_red, &ctx->shard_edge_buf, &ctx->shard_left_buf,
-                      &ctx->shard_part_buf, &ctx->shard_gather_buf})
+                      &ctx->shard_part_buf, &ctx->shard_gather_buf, &ctx->stage_b})
         b->release();
     for (void *p : ctx->rate_allocs) (void)hipFree(p);
     delete ctx->shard_group;
     for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
     if (ctx->side) { (void)hipStreamSynchronize(ctx->side); (void)hipStreamDestroy(ctx->side); }
+    if (ctx->copy) { (void)hipStreamSynchronize(ctx->copy); (void)hipStreamDestroy(ctx->copy); }
+    for (auto &e : ctx->ev_staged) if (e) (void)hipEventDestroy(e);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -1246,16 +1308,10 @@ try {
     // most 96 GiB) -- a launch that fills several rounds of the GPU's wave slots wastes less on its last, partial round
     size_t widen_limit = 16 * ctx->cfg.stage_bytes;
     bool widen_probed = false;
-    int fatal = HR_OK;
+    std::vector<std::vector<size_t>> groups;
     auto flush = [&]() {
         cur_widened = 0;
-        if (cur.empty() || fatal) { cur.clear(); cur_bytes = 0; return; }
-        const int rc = analyze_group(ctx, tracks, cur, out);
-        if (rc) {
-            // a failing group marks its own tracks; HIP errors are fatal for the call
-            for (size_t i : cur) out[i].status = rc;
-            if (rc == HR_ERR_HIP) fatal = rc;
-        }
+        if (!cur.empty()) groups.push_back(cur);
         cur.clear();
         cur_bytes = 0;
     };
@@ -1282,6 +1338,44 @@ try {
         cur_widened += wbytes;
     }
     flush();
+    // The groups, pipelined: while group k is measured, the staging copies of group k + 1 run on the copy stream into the other
+    // staging buffer (group k - 1, which used it, has been finished).  A failing group marks its own tracks; HIP errors are
+    // fatal for the call.
+    int fatal = HR_OK;
+    // (an exception on the way -- std::bad_alloc from a host container -- must not free the jobs' result buffers under copies
+    // that are still in flight: the streams are drained before the jobs go)
+    struct Drain {
+        hr_ctx *c;
+        bool armed = true;
+        ~Drain()
+        {
+            if (!armed) return;
+            (void)hipStreamSynchronize(c->stream);
+            if (c->copy) (void)hipStreamSynchronize(c->copy);
+        }
+    } drain{ctx};
+    std::vector<GroupJob> jobs(groups.size());
+    std::vector<int> staged(groups.size(), HR_OK);
+    auto fail = [&](size_t k, int rc) {
+        for (size_t i : groups[k]) out[i].status = rc;
+        if (rc == HR_ERR_HIP) fatal = rc;
+        (void)hipStreamSynchronize(ctx->stream);  // (nothing queued for this group may outlive its host buffers)
+        if (ctx->copy) (void)hipStreamSynchronize(ctx->copy);
+    };
+    for (size_t k = 0; k < groups.size(); k++) { jobs[k].idx = groups[k]; jobs[k].half = static_cast<int>(k & 1); }
+    if (!groups.empty()) staged[0] = group_stage(ctx, tracks, jobs[0]);
+    size_t k_done = 0;  // groups that have had their turn
+    for (size_t k = 0; k < groups.size() && !fatal; k++, k_done++) {
+        int rc = staged[k];
+        if (!rc) rc = group_launch(ctx, tracks, jobs[k]);
+        if (k + 1 < groups.size()) staged[k + 1] = group_stage(ctx, tracks, jobs[k + 1]);
+        if (!rc) rc = group_finish(ctx, tracks, jobs[k], out);
+        if (rc) fail(k, rc);
+        jobs[k] = GroupJob{};  // (its descriptors and result copies are not needed any more)
+    }
+    for (size_t k = k_done; k < groups.size(); k++)  // (after a fatal error: the groups that never ran)
+        for (size_t i : groups[k]) out[i].status = fatal;
+    drain.armed = fatal != HR_OK;
     return fatal;
 } HR_CATCH_ALL
 

@@ -193,7 +193,7 @@ def shard_halos(dist, meter, shard_spec, rank, active):
 
 
 def analyze_stream_shard_device(dist, meter, shard_spec, rank, active, channels, first_hop=0, halos=None, bufs=None,
-                                shared_stream=False, timings=None):
+                                shared_stream=False, timings=None, align_phases=False):
     """One rank's part of a time-sharded stream with the exchange records resident on the device (hr_shard_pass1_device /
     hr_shard_pass2_device / hr_shard_finish_gathered; every gating mode but GATE_EXACT).  Per call: one neighbour
     send / receive of the edge, one all-gather of the partial, one synchronisation (inside the finish).  Over "nccl" the
@@ -201,7 +201,9 @@ def analyze_stream_shard_device(dist, meter, shard_spec, rank, active, channels,
     host memory.  `halos` = (left_tail, right_head) from shard_halos() or from whoever cut the stream; None: fetched here.
     shared_stream: the meter was created on torch's current stream (Meter(stream=torch.cuda.current_stream().cuda_stream)),
     so the collectives and the library's kernels are ordered on it and nothing waits on the host between the phases;
-    otherwise the two are ordered through synchronisations.  Every rank of the group must call this."""
+    otherwise the two are ordered through synchronisations.  align_phases (timing runs on a shared device): a barrier in front
+    of each of the two exchange steps, so that `timings` shows what the exchange itself costs and not how long a rank waited
+    for a neighbour whose kernels were queued behind its own.  Every rank of the group must call this."""
     import time
 
     import torch
@@ -229,6 +231,10 @@ def analyze_stream_shard_device(dist, meter, shard_spec, rank, active, channels,
         meter.shard_pass1_device(shard_spec, halos[0], halos[1], first_hop, bufs.edge.data_ptr())
         order()  # (where the streams are brought together on the host, the kernels' time shows up in this phase)
         lap("pass1")
+    if align_phases:
+        dist.barrier()
+        lap("wait_for_slowest_rank")
+    if mine:
         ops = []
         if on_gpu:
             if rank + 1 < active:
@@ -253,6 +259,9 @@ def analyze_stream_shard_device(dist, meter, shard_spec, rank, active, channels,
         lap("pass2")
     else:
         bufs.part.copy_(bufs.idle)
+    if align_phases:
+        dist.barrier()
+        lap("wait_for_slowest_rank")
     while True:
         if on_gpu:
             dist.all_gather_into_tensor(bufs.gathered, bufs.part)

@@ -76,7 +76,9 @@ typedef struct hr_config {
                            split into stereo planes first instead of being read directly (the path of rounds 1-2; same
                            results bit for bit, for tests and A/B timing) */
     void *stream;       /* hipStream_t to run on, or NULL for a stream owned by the context */
-    uint64_t stage_bytes; /* device staging for host-resident PCM; 0 = default (1 GiB)      */
+    uint64_t stage_bytes; /* device staging for host-resident PCM per launch group; 0 = default (1 GiB).  A batch that
+                             needs more is measured group by group, the copies of the next group (on a stream of
+                             their own, into a second buffer of this size) running beside the kernels of this one */
 } hr_config;
 
 /* One decoded audio stream (the first audio stream of a file: `-map 0:a:0`, analyzer.rs:258). */
