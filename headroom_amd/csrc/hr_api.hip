@@ -281,6 +281,7 @@ int validate_track(const hr_ctx *ctx, const hr_track &t)
 }
 
 bool fused_mc(const hr_ctx *ctx, const hr_track &t, const void *dev);  // (below, beside the other routing predicates)
+bool fused_mc4(const hr_ctx *ctx, const TrackDesc &d, int tp_class);
 
 // One launch group: descriptors already built in `descs` (host), PCM resident on the device.
 struct Group {
@@ -421,8 +422,9 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                 c.steps[2] = full * t1 + wl * tP;
             }
         }
-        // (an item of a multichannel track read directly is channels / 2 waves)
-        auto wpi_of = [&](size_t i) { return fmc[i] ? static_cast<uint64_t>(g.descs[i].ch / 2) : uint64_t{1}; };
+        // (an item of a multichannel track read directly is a workgroup of its own, and a CU holds two of them, as it holds two
+        // workgroups of four stereo waves: four of the 2048 slots, whether the workgroup is three waves or four)
+        auto wpi_of = [&](size_t i) { return fmc[i] ? uint64_t{4} : uint64_t{1}; };
         // the track's own best: fuller waves must pay for the fixed cost of more rows (3 %); shorter LAST waves cost nothing
         auto own_choice = [&](size_t i) {
             const Cost &c = cost[i];
@@ -548,10 +550,11 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     fitems.clear();
     // items sorted by kernel specialisation: classes 0..5 = K-weight + true peak (tile shape of the rate),
     // class 6 = K-weight only, class 7 = K-weight + sample peak, classes 8..13 / 14..19 = classes 0..5 reading stereo s16 / s24,
-    // classes 20 + 6 (3 [7.1 instead of 5.1] + sample format) + (0..5) = a 5.1 / 7.1 track read directly (fused_mc)
-    constexpr int kStereoClasses = 20, kFusedClasses = kStereoClasses + 36;
+    // classes 20 + 6 (3 [7.1 instead of 5.1] + sample format) + (0..5) = a 5.1 / 7.1 track read directly (fused_mc),
+    // classes 56 + 6 (sample format) + (0..5) = 5.1 read directly by the four-wave workgroup (fused_mc4: three candidate lists per item)
+    constexpr int kStereoClasses = 20, kFourWaveClasses = kStereoClasses + 36, kFusedClasses = kFourWaveClasses + 18;
     size_t class_off[kFusedClasses + 1];
-    auto class_wpi = [&](int cls) -> uint32_t { return cls < kStereoClasses ? 1u : ((cls - kStereoClasses) / 18 ? 4u : 3u); };
+    auto class_wpi = [&](int cls) -> uint32_t { return cls < kStereoClasses ? 1u : cls >= kFourWaveClasses ? 3u : ((cls - kStereoClasses) / 18 ? 4u : 3u); };
     // The four waves of a workgroup share the rate's tables in LDS and run in lock step, so a workgroup never
     // mixes rates or row lengths: every (class, rate, row length) run is padded to a multiple of 4 with n_rows == 0
     // copies of its last item.
@@ -562,7 +565,8 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     for (size_t i = 0; i < nt; i++) {
         if (!fkw[i]) continue;
         const RateDev &rd = ctx->rates_h[g.descs[i].rate_idx];
-        const int mine = fmc[i] ? kStereoClasses + 6 * ((g.descs[i].ch == 8 ? 3 : 0) + g.fmts[i]) + fused_tp_class(rd.tp_mt, rd.tp_last_rows)
+        const int tpc = fused_tp_class(rd.tp_mt, rd.tp_last_rows);
+        const int mine = fmc[i] ? (fused_mc4(ctx, g.descs[i], tpc) ? kFourWaveClasses + 6 * g.fmts[i] + tpc : kStereoClasses + 6 * ((g.descs[i].ch == 8 ? 3 : 0) + g.fmts[i]) + tpc)
                        : ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
         by_class_rate[static_cast<size_t>(mine) * n_rates + g.descs[i].rate_idx].push_back(static_cast<uint32_t>(i));
     }
@@ -745,8 +749,9 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             fsc.cands = static_cast<char *>(fs.cands) + fused_cand_bytes(static_cast<uint32_t>(ctx->h_runs[cls].list_off));
             fsc.cand_cnt = fs.cand_cnt + ctx->h_runs[cls].list_off;
             if (cls >= kStereoClasses) {
-                const int sub = cls - kStereoClasses;
-                launch_fused_mc(sub / 18 ? 8 : 6, (sub / 6) % 3, sub % 6, dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
+                const bool four = cls >= kFourWaveClasses;
+                const int sub = cls - (four ? kFourWaveClasses : kStereoClasses);
+                launch_fused_mc(sub / 18 ? 8 : 6, (sub / 6) % 3, sub % 6, four, dt, dr, fi + off, static_cast<uint32_t>(n), ctx->recs.as<HopRec>(), fsc,
                                 ctx->peaks.as<unsigned long long>(), st);
                 continue;
             }
@@ -990,6 +995,17 @@ bool fused_s16(const hr_ctx *ctx, const hr_track &t, const void *dev)
 // channels / 2 waves shares the rows' pieces) when its rate's tile shape has a build, its rows start on dwords and its buffer on
 // a 16-byte boundary.  Everything else of more than two channels goes through stereo planes (splits()), as all of it did
 // until round 3; hr_config.engine = 5 keeps it that way (A/B and tests).
+// A 5.1 track that fused_mc() takes goes to the four-wave workgroup (hr_fused_core.hpp, ROLE: three waves screen a channel pair
+// each and K-weight its first channel, a fourth wave K-weights two of the second channels) when one of the second channels
+// (1, 3, 5) carries no loudness weight -- the LFE of the default layout -- so that nobody has to K-weight it: its records are
+// written as zeros, which the weight multiplies either way.  Two such workgroups fill the eight wave slots of a CU, where the
+// three-wave workgroup leaves two empty.  hr_config.engine = 6 keeps the three-wave workgroup (A/B and tests).
+bool fused_mc4(const hr_ctx *ctx, const TrackDesc &d, int tp_class)
+{
+    if (ctx->cfg.engine == 6 || d.ch != 6 || !fused_mc4_supported(d.fmt, tp_class)) return false;
+    return d.w[1] == 0.0f || d.w[3] == 0.0f || d.w[5] == 0.0f;
+}
+
 bool fused_mc(const hr_ctx *ctx, const hr_track &t, const void *dev)
 {
     if (t.channels != 6 && t.channels != 8) return false;
@@ -1214,7 +1230,7 @@ try {
     *out = nullptr;
     hr_config c{};
     if (cfg) c = *cfg;
-    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 5) return HR_ERR_INVALID;
+    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 6) return HR_ERR_INVALID;
     const int n = hr_device_count();
     if (n <= 0) return HR_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;

@@ -315,27 +315,49 @@ __device__ __forceinline__ float2 mc_frame_pair(const char *fp, int pair)
     }
 }
 
-template <bool DO_KW, bool DO_TP, int MT, bool SMALL, int INF = 0, int NCH = 2>
-__global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (NCH > 2 ? NCH / 2 : kFusedWaves)) k_fused_f32s(const TrackDesc *__restrict__ tracks,
-                                                       const RateDev *__restrict__ rates,
-                                                       const FusedItem *__restrict__ items, uint32_t n_items,
-                                                       HopRec *__restrict__ recs, uint2 *__restrict__ cands,
-                                                       unsigned *__restrict__ cand_cnt, unsigned *__restrict__ tpb,
-                                                       unsigned *__restrict__ overflow,
-                                                       unsigned long long *__restrict__ peaks, int dbg)
+// one channel of one frame from memory (prologue of the K-weighting wave of a four-wave 5.1 workgroup), fp = the frame's first byte
+template <int INF>
+__device__ __forceinline__ float mc_frame_chan(const char *fp, int c)
+{
+    if constexpr (INF == 2) {
+        const uint8_t *b = reinterpret_cast<const uint8_t *>(fp) + 3 * c;
+        const int32_t x = static_cast<int32_t>(static_cast<uint32_t>(b[0]) << 8 | static_cast<uint32_t>(b[1]) << 16 | static_cast<uint32_t>(b[2]) << 24) >> 8;
+        return static_cast<float>(x) * (1.0f / 8388608.0f);
+    } else if constexpr (INF == 1) {
+        return static_cast<float>(*reinterpret_cast<const int16_t *>(fp + 2 * c)) * (1.0f / 32768.0f);
+    } else {
+        return *reinterpret_cast<const float *>(fp + 4 * c);
+    }
+}
+
+// ROLE (5.1 only, round 3): 0 = every wave of the workgroup does the same work on its own channel pair (the stereo kernel; 5.1 /
+// 7.1 with NCH / 2 waves).  The FOUR-wave 5.1 workgroup splits the work by role instead, so that a CU holds eight balanced
+// waves where three-wave workgroups left two of its eight wave slots empty: ROLE 1 = one of the three screening waves --
+// true-peak screen of its pair, K-weighting of the pair's FIRST channel only; ROLE 2 = the fourth wave -- K-weighting of the
+// second channels (R and Rs of a 5.1 track: the two odd channels that carry loudness weight; the LFE, weight 0, is K-weighted
+// by nobody and gets zero records), no screen.  Same arithmetic per channel in the same order: records, candidates and peaks
+// are those of ROLE 0.
+template <bool DO_KW, bool DO_TP, int MT, bool SMALL, int INF, int NCH, int ROLE>
+__device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restrict__ tracks,
+                                           const RateDev *__restrict__ rates,
+                                           const FusedItem *__restrict__ items, uint32_t n_items,
+                                           HopRec *__restrict__ recs, uint2 *__restrict__ cands,
+                                           unsigned *__restrict__ cand_cnt, unsigned *__restrict__ tpb,
+                                           unsigned *__restrict__ overflow,
+                                           unsigned long long *__restrict__ peaks, int dbg)
 {
     // dbg bit 6 (64, a production switch of the K-weighting-only build): also track the sample peak of the frames read
     // (HR_TP_SAMPLE, and 192 kHz input whose "true peak" is the sample peak)
     // other dbg bits (HR_EXPERIMENTS builds only; results are wrong when set): 1 = never list candidates,
     // 16 = no PCM / carry-table DMA after the first piece, 32 = every piece DMA re-reads piece 0
-    extern __shared__ __attribute__((aligned(16))) char smem[];  // kGroupLds
     constexpr bool MC = NCH > 2;                       // 5.1 / 7.1 read directly: the workgroup's waves share ONE item
-    constexpr int WGW = MC ? NCH / 2 : kFusedWaves;    // waves per workgroup
+    constexpr int WGW = ROLE ? 4 : MC ? NCH / 2 : kFusedWaves;    // waves per workgroup
+    constexpr int NSCR = ROLE ? 3 : WGW;               // of them: waves that screen (share the coefficient DMA, own a candidate list)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint32_t item_idx = MC ? blockIdx.x : blockIdx.x * kFusedWaves + wave;
-    const uint32_t slot_idx = MC ? blockIdx.x * WGW + wave : item_idx;  // this wave's candidate list
-    const int chan0 = MC ? 2 * wave : 0;               // the wave's channels: chan0, chan0 + 1
+    const uint32_t slot_idx = MC ? blockIdx.x * NSCR + wave : item_idx;  // this wave's candidate list
+    const int chan0 = MC ? 2 * wave : 0;               // the wave's channels: chan0, chan0 + 1 (ROLE 2: chA, chB below)
     // (stereo: the host pads every rate's item list to a multiple of 4 with n_rows == 0 items: the four waves of a
     // workgroup share tables and a barrier per step, so all of them run all steps)
     const FusedItem it = items[item_idx];
@@ -343,6 +365,14 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
     const RateDev &r = rates[t.rate_idx];
     const bool passthru0 = r.tp_passthru0 != 0;  // else (BS.1770 bank) the sample peak bounds nothing and phase 0 is screened
     const KCoef kc = r.k;
+    // ROLE 2: the two second channels this wave K-weights (those with loudness weight first), and the one it does not
+    int chA = chan0, chB = chan0 + 1, chZ = -1;
+    if constexpr (ROLE == 2) {
+        int pick[3], n = 0;
+        for (int c = 1; c < NCH; c += 2) if (t.w[c] != 0.0f) pick[n++] = c;
+        for (int c = 1; c < NCH; c += 2) if (t.w[c] == 0.0f) pick[n++] = c;
+        chA = pick[0]; chB = pick[1]; chZ = pick[2];
+    }
     // (Measured and dropped, round 3: not K-weighting a channel without loudness weight -- the LFE of 5.1 / 7.1.  The waves of
     // a workgroup step in lock step, so the wave that holds it only waits longer at the barrier, and the wave-uniform branch
     // around every sample's K-weighting cost all waves 6 %: 355 against 378 audio-hours/s on BASELINE configs[3].)
@@ -405,7 +435,8 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
     }
     const unsigned rd_swz = INF == 2 ? (lane >> 3) & 1 : INF == 1 ? (lane >> 2) & 3 : (lane >> 1) & 7;  // s24: a rotation, not an xor (stereo only)
     // stereo: this lane's row in the wave's piece buffer; MC: this lane's row in buffer 0, at the first byte of the wave's channel pair
-    const char *my_lds = MC ? lbuf + lane * (NS * 16) + wave * (FB / NCH * 2) : lbuf + lane * PB;
+    // (ROLE 2: at the row's first byte)
+    const char *my_lds = ROLE == 2 ? lbuf + lane * (NS * 16) : MC ? lbuf + lane * (NS * 16) + wave * (FB / NCH * 2) : lbuf + lane * PB;
     // MC, one piece set: this wave's share of the DMA instructions into buffer `half` (lanes with nothing to fetch stay out)
     auto mc_issue = [&](const char *src, int half) {
 #pragma unroll
@@ -456,7 +487,7 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
                     for (int mt = 0; mt < MT; mt++)
 #pragma unroll
                         for (int ksx = 0; ksx < 3; ksx++)
-                            if (((V * 3 * MT + mt * 3 + ksx) % WGW) == wave)
+                            if (((V * 3 * MT + mt * 3 + ksx) % NSCR) == wave)
                                 dma16(asrc + (mt * 3 + ksx) * 1024, lane16, abuf + V * RS + (mt * 3 + (V + 1 + ksx) % 3) * 1024);
             }
         }
@@ -475,7 +506,10 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
         if (it.frame0 > 0 || row > 0) {  // (not the track's first row)
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                if constexpr (MC) {
+                if constexpr (ROLE == 2) {
+                    const char *f0 = rowc + (-16 + 2 * c) * static_cast<int>(FB), *f1 = rowc + (-15 + 2 * c) * static_cast<int>(FB);
+                    v[c] = make_float4(mc_frame_chan<INF>(f0, chA), mc_frame_chan<INF>(f0, chB), mc_frame_chan<INF>(f1, chA), mc_frame_chan<INF>(f1, chB));
+                } else if constexpr (MC) {
                     const float2 a = mc_frame_pair<INF>(rowc + (-16 + 2 * c) * static_cast<int>(FB), wave);
                     const float2 b = mc_frame_pair<INF>(rowc + (-15 + 2 * c) * static_cast<int>(FB), wave);
                     v[c] = make_float4(a.x, a.y, b.x, b.y);
@@ -493,15 +527,18 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
         } else if (t.left_tail) {
 #pragma unroll
             for (int c = 0; c < 8; c++)
-                v[c] = make_float4(static_cast<float>(t.left_tail[(2 * c) * NCH + chan0 + 0]), static_cast<float>(t.left_tail[(2 * c) * NCH + chan0 + 1]),
-                                   static_cast<float>(t.left_tail[(2 * c + 1) * NCH + chan0 + 0]), static_cast<float>(t.left_tail[(2 * c + 1) * NCH + chan0 + 1]));
+                v[c] = make_float4(static_cast<float>(t.left_tail[(2 * c) * NCH + chA]), static_cast<float>(t.left_tail[(2 * c) * NCH + chB]),
+                                   static_cast<float>(t.left_tail[(2 * c + 1) * NCH + chA]), static_cast<float>(t.left_tail[(2 * c + 1) * NCH + chB]));
             ks[0].x1 = v[7].z; ks[1].x1 = v[7].w;
             ks[0].x2 = v[7].x; ks[1].x2 = v[7].y;
         } else if (t.tp_reflect) {
             // start of the stream: libswresample reflects, x[-j] = x[j]; the K-weighting starts from silence
 #pragma unroll
             for (int c = 0; c < 8; c++) {
-                if constexpr (MC) {
+                if constexpr (ROLE == 2) {
+                    // (the reflected frames only matter to the screen; this wave K-weights from silence and needs none of them)
+                    v[c] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                } else if constexpr (MC) {
                     const float2 a = mc_frame_pair<INF>(rowc + (16 - 2 * c) * static_cast<int>(FB), wave);
                     const float2 b = mc_frame_pair<INF>(rowc + (15 - 2 * c) * static_cast<int>(FB), wave);
                     v[c] = make_float4(a.x, a.y, b.x, b.y);
@@ -604,7 +641,7 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
         for (int mt = 0; mt < MT; mt++)
 #pragma unroll
             for (int ksx = 0; ksx < 3; ksx++)
-                if (((mt * 3 + ksx) % WGW) == wave)
+                if (((mt * 3 + ksx) % NSCR) == wave)
                     dma16(asrc + (mt * 3 + ksx) * 1024, lane16, dst + (mt * 3 + (kmod3 + 2 + ksx) % 3) * 1024);
     };
 
@@ -632,7 +669,36 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
         __builtin_amdgcn_s_barrier();
         // MC: this lane's row, at the wave's channel pair, in the buffer that holds piece k
         const char *ml = MC ? my_lds + (k & 1) * kMcPiece : my_lds;
-        if constexpr (MC && INF == 2) {
+        if constexpr (ROLE == 2 && INF == 2) {
+            // One 24-bit sample of channel c of frame f starts at byte FB f + 3 c of the row: inside the two dwords from the dword
+            // boundary below it, s = (FB f + 3 c) & 3 bytes in.  c is wave-uniform, the parity of FB f compile time: per channel
+            // two bases (even / odd frames), immediate offsets, a wave-uniform shift each.
+            auto sample = [&](auto fc, int c) {
+                constexpr int f = decltype(fc)::value;
+                constexpr unsigned e = (FB * f) & 3u;  // 0 or 2
+                const unsigned sft = (e + 3u * static_cast<unsigned>(c)) & 3u;
+                const unsigned *q = reinterpret_cast<const unsigned *>(ml + 3 * c - static_cast<int>(sft) + static_cast<int>(FB * f));
+                const unsigned bits = __funnelshift_r(q[0], q[1], 8u * sft);
+                return static_cast<float>(static_cast<int>(bits << 8) >> 8) * (1.0f / 8388608.0f);
+            };
+#define HR_MC_CH(c) { using F0 = std::integral_constant<int, 2 * (c)>; using F1 = std::integral_constant<int, 2 * (c) + 1>; \
+                      v[c] = make_float4(sample(F0{}, chA), sample(F0{}, chB), sample(F1{}, chA), sample(F1{}, chB)); }
+            HR_MC_CH(0) HR_MC_CH(1) HR_MC_CH(2) HR_MC_CH(3) HR_MC_CH(4) HR_MC_CH(5) HR_MC_CH(6) HR_MC_CH(7)
+#undef HR_MC_CH
+        } else if constexpr (ROLE == 2) {
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                const char *f0 = ml + FB * (2 * c), *f1 = ml + FB * (2 * c + 1);
+                if constexpr (INF == 1) {
+                    constexpr float sc = 1.0f / 32768.0f;
+                    v[c] = make_float4(static_cast<float>(*reinterpret_cast<const int16_t *>(f0 + 2 * chA)) * sc, static_cast<float>(*reinterpret_cast<const int16_t *>(f0 + 2 * chB)) * sc,
+                                       static_cast<float>(*reinterpret_cast<const int16_t *>(f1 + 2 * chA)) * sc, static_cast<float>(*reinterpret_cast<const int16_t *>(f1 + 2 * chB)) * sc);
+                } else {
+                    v[c] = make_float4(*reinterpret_cast<const float *>(f0 + 4 * chA), *reinterpret_cast<const float *>(f0 + 4 * chB),
+                                       *reinterpret_cast<const float *>(f1 + 4 * chA), *reinterpret_cast<const float *>(f1 + 4 * chB));
+                }
+            }
+        } else if constexpr (MC && INF == 2) {
             // Packed s24: the pair's six bytes of frame f start at ml + FB f, on an even byte.  They lie inside the two dwords
             // from the dword boundary below them; which boundary that is depends on the parity of the pair (6 p mod 4 = 0 or
             // 2, wave-uniform) and, for 5.1 (FB = 18), of the frame (compile time): two bases, immediate offsets, and a
@@ -708,7 +774,9 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
             const char *gk = gbuf + (k & 1) * kCarryLds;
             for (int i = 0; i < rem; i++) {
                 float2 x;
-                if constexpr (MC && INF == 2) {
+                if constexpr (ROLE == 2) {
+                    x = make_float2(mc_frame_chan<INF>(ml + FB * i, chA), mc_frame_chan<INF>(ml + FB * i, chB));
+                } else if constexpr (MC && INF == 2) {
                     uint8_t fb[6];
 #pragma unroll
                     for (int bb = 0; bb < 6; bb++) fb[bb] = *reinterpret_cast<const uint8_t *>(ml + FB * i + bb);
@@ -735,11 +803,11 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
                 if constexpr (!SHORT) {
                     const G4 g4 = lds_g4(gk + i * 32);
                     kw_sample(ks[0], kc, x.x, g4);
-                    kw_sample(ks[1], kc, x.y, g4);
+                    if constexpr (ROLE != 1) kw_sample(ks[1], kc, x.y, g4);
                 } else {
                     const double2 g = *reinterpret_cast<const double2 *>(gk + i * 32 + 16);
                     kw_sample_short(ks[0], kc, x.x, g.x, g.y);
-                    kw_sample_short(ks[1], kc, x.y, g.x, g.y);
+                    if constexpr (ROLE != 1) kw_sample_short(ks[1], kc, x.y, g.x, g.y);
                 }
             }
         }
@@ -900,6 +968,7 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
             };
             // sample i of slice c: i = 0, 1 are the two channels of frame 2c, i = 2, 3 of frame 2c+1
             auto ksample = [&](int c, int i, const GC &g) {
+                if (ROLE == 1 && (i & 1)) return;  // (a screening wave of the four-wave workgroup K-weights its pair's first channel only)
                 const float x = i == 0 ? v[c].x : i == 1 ? v[c].y : i == 2 ? v[c].z : v[c].w;
                 const double2 g23 = as_double2(g.r[i < 2 ? 1 : 3]);
                 if constexpr (!SHORT) {
@@ -1079,15 +1148,21 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
 
     if (DO_KW && lane < n_rows && h < t.sub_from + (t.n_hops - t.sub_from) * t.parts) {  // (rows behind the last hop are there for their peak only)
 #pragma unroll
-        for (int c = 0; c < 2; c++) {
+        for (int c = 0; c < (ROLE == 1 ? 1 : 2); c++) {
             if (k_short <= T) {
                 ks[c].q0 += fma(r.q_ab[0][0], ks[c].q2, r.q_ab[0][1] * ks[c].q3);
                 ks[c].q1 += fma(r.q_ab[1][0], ks[c].q2, r.q_ab[1][1] * ks[c].q3);
             }
-            HopRec &o = recs[t.rec_base + (kPreRec + h) * NCH + chan0 + c];
+            HopRec &o = recs[t.rec_base + (kPreRec + h) * NCH + (c ? chB : chA)];
             o.e0 = ks[c].e0;
             o.q[0] = ks[c].q0; o.q[1] = ks[c].q1; o.q[2] = ks[c].q2; o.q[3] = ks[c].q3;
             o.s[0] = ks[c].y1; o.s[1] = ks[c].y1 - ks[c].y2; o.s[2] = ks[c].z1; o.s[3] = ks[c].z1 - ks[c].z2;
+        }
+        if constexpr (ROLE == 2) {  // the second channel nobody K-weights (no loudness weight: the LFE): zero records, not stale ones
+            HopRec &o = recs[t.rec_base + (kPreRec + h) * NCH + chZ];
+            o.e0 = 0.0;
+#pragma unroll
+            for (int j = 0; j < 4; j++) { o.q[j] = 0.0; o.s[j] = 0.0; }
         }
     }
     if constexpr (!DO_TP) {
@@ -1129,6 +1204,39 @@ __global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (N
             }
         }
     }
+}
+
+// every wave of the workgroup the same work on its own item (stereo) or channel pair (5.1 / 7.1, NCH / 2 waves)
+template <bool DO_KW, bool DO_TP, int MT, bool SMALL, int INF = 0, int NCH = 2>
+__global__ void __launch_bounds__(64 * (NCH > 2 ? NCH / 2 : kFusedWaves), 8 / (NCH > 2 ? NCH / 2 : kFusedWaves)) k_fused_f32s(const TrackDesc *__restrict__ tracks,
+                                                       const RateDev *__restrict__ rates,
+                                                       const FusedItem *__restrict__ items, uint32_t n_items,
+                                                       HopRec *__restrict__ recs, uint2 *__restrict__ cands,
+                                                       unsigned *__restrict__ cand_cnt, unsigned *__restrict__ tpb,
+                                                       unsigned *__restrict__ overflow,
+                                                       unsigned long long *__restrict__ peaks, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];  // kGroupLds
+    fused_body<DO_KW, DO_TP, MT, SMALL, INF, NCH, 0>(smem, tracks, rates, items, n_items, recs, cands, cand_cnt, tpb, overflow, peaks, dbg);
+}
+
+// 5.1 with FOUR waves per workgroup: three screening waves (ROLE 1) and one K-weighting wave (ROLE 2); two workgroups fill
+// the eight wave slots of a CU
+template <int MT, bool SMALL, int INF>
+__global__ void __launch_bounds__(256, 2) k_fused_51x4(const TrackDesc *__restrict__ tracks, const RateDev *__restrict__ rates,
+                                                       const FusedItem *__restrict__ items, uint32_t n_items,
+                                                       HopRec *__restrict__ recs, uint2 *__restrict__ cands,
+                                                       unsigned *__restrict__ cand_cnt, unsigned *__restrict__ tpb,
+                                                       unsigned *__restrict__ overflow,
+                                                       unsigned long long *__restrict__ peaks, int dbg)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (measured and dropped: rotating which hardware wave takes ROLE 2 by workgroup index, so that the K-weighting waves of a
+    // CU's two workgroups sit on different SIMDs -- 7.25 ms either way on BASELINE configs[3])
+    if (__builtin_amdgcn_readfirstlane(threadIdx.x >> 6) < 3)
+        fused_body<true, true, MT, SMALL, INF, 6, 1>(smem, tracks, rates, items, n_items, recs, cands, cand_cnt, tpb, overflow, peaks, dbg);
+    else
+        fused_body<true, false, MT, SMALL, INF, 6, 2>(smem, tracks, rates, items, n_items, recs, cands, cand_cnt, tpb, overflow, peaks, dbg);
 }
 
 }  // namespace hr

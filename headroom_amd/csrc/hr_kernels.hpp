@@ -69,7 +69,13 @@ void launch_refine_cands(const TrackDesc *tracks, const RateDev *rates, const Fu
 // workgroup of channels / 2 waves; fs.cands / fs.cand_cnt hold channels / 2 lists per item).  fused_mc_supported: is there a
 // build for this channel count, sample format (HR_FMT_F32 / S16 / S24) and true-peak class?
 bool fused_mc_supported(int channels, int fmt, int tp_class);
-void launch_fused_mc(int channels, int fmt, int tp_class, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
+bool fused_mc4_supported(int fmt, int tp_class);
+// hr_kernels_fused_mc4.hip: the four-wave 5.1 kernel alone (launch_fused_mc() follows it with the refine kernel)
+void launch_fused_mc4(int fmt, int tp_class, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items, uint32_t n_items,
+                      HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, hipStream_t st);
+// four_waves (5.1 only, where fused_mc4_supported()): the workgroup is three screening waves + one K-weighting wave (hr_fused_core.hpp, ROLE) instead of three
+// waves that do both; same lists (three per item), same records, same results
+void launch_fused_mc(int channels, int fmt, int tp_class, bool four_waves, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
                      uint32_t n_items, HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, hipStream_t st);
 // All items of one launch share a true-peak class (the kernel is specialised on the tile shape of the rate).
 int fused_tp_class(int tp_mt, int tp_last_rows);

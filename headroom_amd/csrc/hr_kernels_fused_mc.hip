@@ -51,10 +51,15 @@ bool fused_mc_supported(int channels, int fmt, int tp_class)
     return tp_class == 0 || tp_class == 2 || tp_class == 5;
 }
 
-void launch_fused_mc(int channels, int fmt, int tp_class, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
+void launch_fused_mc(int channels, int fmt, int tp_class, bool four_waves, const TrackDesc *tracks, const RateDev *rates, const FusedItem *items,
                      uint32_t n_items, HopRec *recs, const FusedScratch &fs, unsigned long long *peaks, hipStream_t st)
 {
     if (!n_items || !fused_mc_supported(channels, fmt, tp_class)) return;
+    if (four_waves && channels == 6) {
+        launch_fused_mc4(fmt, tp_class, tracks, rates, items, n_items, recs, fs, peaks, st);
+        launch_refine_cands(tracks, rates, items, n_items * 3u, 3u, fs, peaks, st);
+        return;
+    }
 #define HR_MC_FMT(NCH)                                                                                                  \
     do {                                                                                                                \
         if (fmt == kFmtS24) launch_mc_class<2, NCH>(tp_class, tracks, rates, items, n_items, recs, fs, peaks, st);       \

@@ -85,6 +85,26 @@ def test_direct_read_equals_planes_and_oracle(oracle, meters, fs, ch, kind, tp):
     planes = meters(5, tp).analyze_batch([spec])[0]
     identical(direct, planes)
     against_oracle(oracle, direct, data, fs, tp=tp, weights=w, **kw)
+    if ch == 6:  # engine 0 took the four-wave workgroup (the LFE has no weight), engine 6 keeps the three-wave one: same rows
+        three = meters(6, tp).analyze_batch([spec])[0]
+        assert {k: direct[k] for k in FLOAT_KEYS + ("n_blocks", "n_gated", "peak_per_ch") if direct[k] == direct[k]} == \
+               {k: three[k] for k in FLOAT_KEYS + ("n_blocks", "n_gated", "peak_per_ch") if three[k] == three[k]}
+
+
+@pytest.mark.parametrize("kind", ["s24", "f32", "s16"])
+@pytest.mark.parametrize("weights", [[1, 0, 1, 1, 1.41, 1.41], [1, 1, 1, 0.5, 1.41, 0], [1, 0, 1, 0, 1, 1.41], [0, 0, 0, 0, 0, 1],
+                                     [1, 1, 1, 0.25, 1.41, 1.41], [1, 0, 0, 0, 1, 0]])
+def test_four_wave_5_1_picks_the_weighted_second_channels(oracle, meters, kind, weights):
+    """The four-wave 5.1 workgroup K-weights, of channels 1 / 3 / 5, the two that carry loudness weight, whichever they are; a
+    layout that weights all three stays on the three-wave workgroup.  96 kHz rows and 44.1 kHz rows (odd hop bytes)."""
+    for fs in (96000, 44100):
+        pcm = noise_track(fs + int(sum(weights) * 100), fs, 6, 7.1, ragged=501)
+        data, kw = as_format(pcm, kind)
+        spec = hr.TrackSpec(data, fs, weights=weights, **kw)
+        got = meters(0).analyze_batch([spec])[0]
+        identical(got, meters(6).analyze_batch([spec])[0])
+        identical(got, meters(5).analyze_batch([spec])[0])
+        against_oracle(oracle, got, data, fs, weights=weights, **kw)
 
 
 def test_config4_shape_with_every_row_length(oracle, meters):
@@ -96,7 +116,7 @@ def test_config4_shape_with_every_row_length(oracle, meters):
     spec = hr.TrackSpec(data, fs, weights=W51, **kw)
     planes = meters(5).analyze_batch([spec])[0]
     against_oracle(oracle, planes, data, fs, weights=W51, **kw)
-    for engine in (0, 2, 3, 4):
+    for engine in (0, 2, 3, 4, 6):
         got = meters(engine).analyze_batch([spec])[0]
         assert got["peak_per_ch"] == planes["peak_per_ch"] and got["n_gated"] == planes["n_gated"]
         assert abs(got["integrated_lufs"] - planes["integrated_lufs"]) < 1e-9   # (other row lengths: other summation trees)
