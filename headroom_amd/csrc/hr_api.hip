@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <new>
 #include <limits>
@@ -150,6 +151,17 @@ struct hr_ctx {
     hipStream_t copy = nullptr;
     hipEvent_t ev_staged[2] = {nullptr, nullptr};
     float last_total_ms = 0, last_main_ms = 0;
+    // HR_HOST_TIMING=1: where the host's time of an hr_analyze_batch call goes (stderr, one line per call)
+    bool host_timing = false;
+    std::chrono::steady_clock::time_point ht_last;
+    std::vector<std::pair<const char *, double>> ht_marks;
+    void ht(const char *what)
+    {
+        if (!host_timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        ht_marks.emplace_back(what, std::chrono::duration<double, std::milli>(now - ht_last).count());
+        ht_last = now;
+    }
 
     size_t comb_n = 0;  // combine work items of the last run_measure (comb_items_d)
 
@@ -543,8 +555,10 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             fend[i] = last_hop0 + 16 * (ftp[i] ? std::min<uint64_t>(keep / 16, T) : T - 2);
         }
     }
+    ctx->ht("plan rows");
     int rc = upload(ctx->tracks_d, g.descs.data(), nt * sizeof(TrackDesc), st);
     if (rc) return rc;
+    ctx->ht("upload descs");
     const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
     std::vector<FusedItem> &fitems = ctx->h_fitems;
     fitems.clear();
@@ -611,10 +625,12 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         }
     }
     class_off[kFusedClasses] = fitems.size();
+    ctx->ht("fused items");
     if (!fitems.empty()) {
         rc = upload(ctx->fitems_d, fitems.data(), fitems.size() * sizeof(FusedItem), st);
         if (rc) return rc;
     }
+    ctx->ht("upload fused items");
 
     // candidate lists: one per wave of the launch
     ctx->h_runs.clear();
@@ -690,6 +706,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     const WorkItem *di = ctx->items_d.as<WorkItem>();
     ctx->h_ftp.assign(ftp.begin(), ftp.end());
+    ctx->ht("generic items + upload");
 
     HIPCHK(hipEventRecord(ctx->ev[0], st));
     if (do_peaks) HIPCHK(hipMemsetAsync(ctx->peaks.p, 0, nt * kMaxCh * sizeof(unsigned long long), st));
@@ -763,6 +780,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         }
     }
     HIPCHK(hipEventRecord(ctx->ev[3], st));
+    ctx->ht("launch fused");
     // The fused kernel is on its way: the host builds the combine kernel's work items beside it (one per 256 (hop, channel)
     // pairs: the bulk of the generic items); their upload queues behind the fused kernel, where the combine kernel follows
     std::vector<WorkItem> &citems = ctx->h_comb_items;
@@ -798,33 +816,51 @@ int run_gating(hr_ctx *ctx, Group &g, bool finalize, bool range_parts = false)
     hipStream_t st = ctx->stream;
     const uint32_t nt = static_cast<uint32_t>(g.descs.size());
     if (!nt) return HR_OK;
-    const size_t hist_bytes = static_cast<size_t>(nt) * kEbuBins * sizeof(uint32_t);
-    if (!ctx->hist.ensure(hist_bytes) || !ctx->outs.ensure(static_cast<size_t>(nt) * sizeof(TrackOut)) ||
-        !ctx->gate_parts.ensure(static_cast<size_t>(g.part_slots) * sizeof(GatePart)) ||
-        ((finalize || range_parts) && !ctx->st_hist.ensure(hist_bytes)))
+    // Whole tracks of a few chunks (finalize, not a time shard's partial statistics) are gated by one workgroup each with the
+    // histograms in LDS (k_gate_small); longer ones and shards chunk by chunk through `hist` / `st_hist` in global memory.
+    const bool small_ok = finalize && !range_parts;
+    auto is_small = [&](uint32_t i) { return small_ok && g.descs[i].n_parts <= kGateSmallParts; };
+    uint32_t n_long = 0;
+    for (uint32_t i = 0; i < nt; i++) n_long += is_small(i) ? 0u : 1u;
+    const uint32_t n_small = nt - n_long;
+    const size_t hist_bytes = n_long ? static_cast<size_t>(nt) * kEbuBins * sizeof(uint32_t) : 0;
+    if (!ctx->outs.ensure(static_cast<size_t>(nt) * sizeof(TrackOut)) || !ctx->gate_parts.ensure(static_cast<size_t>(g.part_slots) * sizeof(GatePart)) ||
+        (n_long && (!ctx->hist.ensure(hist_bytes) || ((finalize || range_parts) && !ctx->st_hist.ensure(hist_bytes)))))
         return HR_ERR_OOM;
-    // one workgroup per chunk of kGateChunk blocks: a 3-minute track is one chunk, a 10-hour stream 176
+    // one workgroup per chunk of kGateChunk blocks: a 10-hour stream is 176 chunks; behind them the lists of the long and of
+    // the small tracks (WorkItem::track)
     std::vector<WorkItem> &items = ctx->h_gate_items;  // (outlives the asynchronous copy)
     items.clear();
     for (uint32_t i = 0; i < nt; i++)
-        for (uint32_t c = 0; c < g.descs[i].n_parts; c++) items.push_back({i, c, static_cast<uint64_t>(c) * kGateChunk});
+        if (!is_small(i))
+            for (uint32_t c = 0; c < g.descs[i].n_parts; c++) items.push_back({i, c, static_cast<uint64_t>(c) * kGateChunk});
+    const uint32_t ni = static_cast<uint32_t>(items.size());
+    if (n_small)  // (no small tracks: the per-track kernels take tracks 0 .. nt - 1 as they are)
+        for (int small = 0; small < 2; small++)
+            for (uint32_t i = 0; i < nt; i++)
+                if (is_small(i) == (small == 1)) items.push_back({i, 0, 0});
     int rc = upload(ctx->gate_items, items.data(), items.size() * sizeof(WorkItem), st);
     if (rc) return rc;
     const TrackDesc *dt = ctx->tracks_d.as<TrackDesc>();
     const WorkItem *di = ctx->gate_items.as<WorkItem>();
-    const uint32_t ni = static_cast<uint32_t>(items.size());
-    HIPCHK(hipMemsetAsync(ctx->hist.p, 0, hist_bytes, st));
-    launch_block_hist(dt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
-                      ctx->ebu_edges.as<double>(), ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), st);
-    launch_gate_final(dt, nt, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
-                      ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
-                      ctx->gate_parts.as<GatePart>(), !finalize, ctx->outs.as<TrackOut>(), st);
-    if (finalize || range_parts) {
-        HIPCHK(hipMemsetAsync(ctx->st_hist.p, 0, hist_bytes, st));
-        launch_range_stats(dt, nt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
-                           ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->st_hist.as<uint32_t>(),
-                           ctx->gate_parts.as<GatePart>(), finalize, ctx->outs.as<TrackOut>(), st);
+    const WorkItem *long_list = n_small ? di + ni : nullptr, *small_list = di + ni + n_long;
+    if (n_long) {
+        HIPCHK(hipMemsetAsync(ctx->hist.p, 0, hist_bytes, st));
+        launch_block_hist(dt, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->ln_bounds.as<double>(),
+                          ctx->ebu_edges.as<double>(), ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(), ctx->gate_parts.as<GatePart>(), st);
+        launch_gate_final(dt, n_long, ctx->cfg.gate_mode, ctx->blk_powers.as<double>(), ctx->hist.as<uint32_t>(),
+                          ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
+                          ctx->gate_parts.as<GatePart>(), !finalize, ctx->outs.as<TrackOut>(), st, long_list);
+        if (finalize || range_parts) {
+            HIPCHK(hipMemsetAsync(ctx->st_hist.p, 0, hist_bytes, st));
+            launch_range_stats(dt, n_long, di, ni, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
+                               ctx->ln_bounds.as<double>(), ctx->ln_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->st_hist.as<uint32_t>(),
+                               ctx->gate_parts.as<GatePart>(), finalize, ctx->outs.as<TrackOut>(), st, long_list);
+        }
     }
+    launch_gate_small(dt, small_list, n_small, ctx->cfg.gate_mode, ctx->hop_sums.as<double>(), ctx->blk_powers.as<double>(),
+                      ctx->ebu_energy.as<double>(), ctx->ebu_edges.as<double>(), ctx->ln_energy.as<double>(), ctx->ln_bounds.as<double>(),
+                      ctx->outs.as<TrackOut>(), st);
     HIPCHK(hipGetLastError());
     return HR_OK;
 }
@@ -1159,10 +1195,13 @@ int group_launch(hr_ctx *ctx, const hr_track *tracks, GroupJob &job)
         job.desc_of[k] = add_track(ctx, job.g, t, dev, reinterpret_cast<float *>(static_cast<char *>(ctx->widened.p) + woff[k]), sp[k] != 0);
         if (job.desc_of[k] < 0) return job.desc_of[k];
     }
+    ctx->ht("add tracks");
     int rc = run_measure(ctx, job.g, true);
     if (rc) return rc;
+    ctx->ht("rest of run_measure");
     rc = run_gating(ctx, job.g, true);
     if (rc) return rc;
+    ctx->ht("run_gating");
     HIPCHK(hipEventRecord(ctx->ev[1], st));
     // the screen's overflow flags come back with the results: one synchronisation in the common case (no flag set)
     rc = overflow_flags_fetch(ctx, job.g);
@@ -1172,6 +1211,7 @@ int group_launch(hr_ctx *ctx, const hr_track *tracks, GroupJob &job)
     job.pk.resize(nt * kMaxCh);
     HIPCHK(hipMemcpyAsync(job.outs.data(), ctx->outs.p, nt * sizeof(TrackOut), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(job.pk.data(), ctx->peaks.p, nt * kMaxCh * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    ctx->ht("queue result copies");
     return HR_OK;
 }
 
@@ -1180,6 +1220,7 @@ int group_finish(hr_ctx *ctx, const hr_track *tracks, GroupJob &job, hr_result *
     hipStream_t st = ctx->stream;
     const size_t nt = job.g.descs.size();
     HIPCHK(hipStreamSynchronize(st));
+    ctx->ht("wait for the GPU");
     bool relaunched = false;
     const int rc = overflow_redo(ctx, job.g, &relaunched);
     if (rc) return rc;
@@ -1195,6 +1236,7 @@ int group_finish(hr_ctx *ctx, const hr_track *tracks, GroupJob &job, hr_result *
         track_peaks(job.g, job.pk, job.desc_of[k], tpk);
         fill_result(ctx, job.outs[job.desc_of[k]], tpk, tracks[job.idx[k]].channels, &out[job.idx[k]]);
     }
+    ctx->ht("results");
     return HR_OK;
 }
 
@@ -1249,6 +1291,7 @@ try {
     if (!ctx->cfg.stage_bytes) ctx->cfg.stage_bytes = 1ull << 30;
 #ifdef HR_EXPERIMENTS  // timing switches of the experiments library (make exp); the shipped library reads none of them
     if (const char *ab = std::getenv("HR_ABLATE")) ctx->ablate = std::atoi(ab);
+    if (const char *e = std::getenv("HR_HOST_TIMING")) ctx->host_timing = std::atoi(e) != 0;
     if (const char *sp = std::getenv("HR_FUSED_SPLIT")) ctx->split = std::atoi(sp) != 0;
     if (const char *se = std::getenv("HR_SERIAL_TAIL")) ctx->serial_tail = std::atoi(se) != 0;
 #endif
@@ -1317,6 +1360,8 @@ try {
     ctx->shard_open = false;  // the workspace an open time shard left behind is about to be reused: its pass 2 must fail
     HIPCHK(hipSetDevice(ctx->cfg.device));
     ctx->last_total_ms = ctx->last_main_ms = 0;
+    ctx->ht_marks.clear();
+    ctx->ht_last = std::chrono::steady_clock::now();
     const double ninf = -std::numeric_limits<double>::infinity();
     std::vector<size_t> cur;
     size_t cur_bytes = 0, cur_widened = 0;
@@ -1354,6 +1399,7 @@ try {
         cur_widened += wbytes;
     }
     flush();
+    ctx->ht("validate + group");
     // The groups, pipelined: while group k is measured, the staging copies of group k + 1 run on the copy stream into the other
     // staging buffer (group k - 1, which used it, has been finished).  A failing group marks its own tracks; HIP errors are
     // fatal for the call.
@@ -1392,6 +1438,11 @@ try {
     for (size_t k = k_done; k < groups.size(); k++)  // (after a fatal error: the groups that never ran)
         for (size_t i : groups[k]) out[i].status = fatal;
     drain.armed = fatal != HR_OK;
+    if (ctx->host_timing) {
+        std::fprintf(stderr, "headroom_hip host timing (ms), %zu tracks:", n);
+        for (const auto &m : ctx->ht_marks) std::fprintf(stderr, " [%s %.3f]", m.first, m.second);
+        std::fprintf(stderr, "\n");
+    }
     return fatal;
 } HR_CATCH_ALL
 

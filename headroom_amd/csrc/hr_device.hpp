@@ -29,6 +29,7 @@ constexpr uint32_t kCandOverflowBit = 0x80000000u;  // in a wave's candidate cou
 // 400 ms blocks (and 3 s windows) per gating workgroup: a 3-minute track (1797 blocks) is one chunk, a 10-hour stream 176 --
 // with 16 384 (rounds 1, 2) that stream kept 22 of the 256 CUs busy for 1.5 ms (profiles/r3_config5_kernel_stats.md)
 constexpr uint32_t kGateChunk = 2048;
+constexpr uint32_t kGateSmallParts = 8;  // tracks of up to this many chunks (27 minutes) are gated by one workgroup each (k_gate_small)
 
 // what one gating chunk hands to the per-track finalisation (summed there in chunk order: reproducible)
 struct GatePart {

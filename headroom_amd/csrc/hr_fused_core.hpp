@@ -349,7 +349,8 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
     // dbg bit 6 (64, a production switch of the K-weighting-only build): also track the sample peak of the frames read
     // (HR_TP_SAMPLE, and 192 kHz input whose "true peak" is the sample peak)
     // other dbg bits (HR_EXPERIMENTS builds only; results are wrong when set): 1 = never list candidates,
-    // 16 = no PCM / carry-table DMA after the first piece, 32 = every piece DMA re-reads piece 0
+    // 16 = no PCM / carry-table DMA after the first piece, 32 = every piece DMA re-reads piece 0, 128 = row bases rounded down to a
+    // cache line (stereo)
     constexpr bool MC = NCH > 2;                       // 5.1 / 7.1 read directly: the workgroup's waves share ONE item
     constexpr int WGW = ROLE ? 4 : MC ? NCH / 2 : kFusedWaves;    // waves per workgroup
     constexpr int NSCR = ROLE ? 3 : WGW;               // of them: waves that screen (share the coefficient DMA, own a candidate list)
@@ -431,6 +432,8 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
                             : INF == 1 ? ((lane & 3) ^ ((slot >> 2) & 3)) : ((lane & 7) ^ ((slot >> 1) & 7));
             const int srow = slot < n_rows ? slot : last_row;
             dma_off[j] = static_cast<unsigned>(srow) * hop * FB + static_cast<unsigned>(chunk) * 16u;
+            // dbg 128 (experiments, results wrong): every row's pieces start on a 128-byte line -- what line-aligned pieces would buy
+            if (HR_DBG(dbg, 128)) dma_off[j] = ((static_cast<unsigned>(srow) * hop * FB) & ~127u) + static_cast<unsigned>(chunk) * 16u;
         }
     }
     const unsigned rd_swz = INF == 2 ? (lane >> 3) & 1 : INF == 1 ? (lane >> 2) & 3 : (lane >> 1) & 7;  // s24: a rotation, not an xor (stereo only)

@@ -23,15 +23,24 @@ void launch_block_hist(const TrackDesc *tracks, const WorkItem *items, uint32_t 
                        const double *ln_bounds, const double *ebu_edges, double *block_powers, uint32_t *hist, GatePart *parts,
                        hipStream_t st);
 // per track: sums the chunks' partial sums into `outs` (tracks with n_parts == 0 bring reduced sums in `outs` already);
-// unless reduce_only, also the relative gate and the gated mean
+// unless reduce_only, also the relative gate and the gated mean.  list (here and in launch_range_stats): the n_tracks tracks
+// the launch is for, by WorkItem::track; nullptr = tracks 0 .. n_tracks - 1
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ebu_edges, const double *ln_energy,
-                       const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st);
+                       const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st,
+                       const WorkItem *list = nullptr);
+// Tracks of at most kGateSmallParts chunks: everything launch_block_hist, launch_gate_final and launch_range_stats (finalize)
+// produce for them, by one workgroup per track with the histograms in LDS -- same results bit for bit, no `hist` / `st_hist`
+// / GatePart traffic (k_gate_small)
+void launch_gate_small(const TrackDesc *tracks, const WorkItem *list, uint32_t n_list, int gate_mode, const double *hop_sums,
+                       double *block_powers, const double *ebu_energy, const double *ebu_edges, const double *ln_energy,
+                       const double *ln_bounds, TrackOut *outs, hipStream_t st);
 // loudness range + maximum 400 ms / 3 s powers (after launch_block_hist: reads the block powers): the chunks' histograms
 // and partial sums, and with `finalize` the per-track result (n_items == 0: only that, from reduced partials)
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
                         const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
-                        const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st);
+                        const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st,
+                        const WorkItem *list = nullptr);
 // hop sums of the stereo planes of a split track -> the track's own (hop, channel) slots; one workgroup per parent
 void launch_gather_planes(const TrackDesc *tracks, const uint32_t *parents, uint32_t n_parents, double *hop_sums, hipStream_t st);
 // libswresample-default resampling to 192 kHz with end flush: dst holds ceil(frames*phases*S/step) interleaved f64 frames

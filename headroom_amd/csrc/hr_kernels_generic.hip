@@ -298,17 +298,22 @@ __global__ void __launch_bounds__(256) k_hop_combine_rows(const TrackDesc *__res
 // ---------------------------------------------------------------------------------------------
 // K2b pass 1: block powers, absolute gate, histogram.  One workgroup per track.
 // ---------------------------------------------------------------------------------------------
+// Sum over the workgroup's 256 threads in the order of the classic shared-memory tree (sh[tid] += sh[tid + s] for s = 128, 64,
+// ... 1), so that results do not depend on who runs it: the two widest stages from LDS, the other six inside wave 0 with
+// cross-lane moves (lane l adds lane l + s: the same pairs), three barriers instead of ten.  Every thread gets the sum.
 __device__ __forceinline__ double block_reduce_sum(double v, double *sh)
 {
-    // fixed-order tree: bit-reproducible from run to run
     const int tid = threadIdx.x;
     sh[tid] = v;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
+    if (tid < 64) {
+        double a = (sh[tid] + sh[tid + 128]) + (sh[tid + 64] + sh[tid + 192]);
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s, 64);  // (lanes >= s add garbage to values nobody reads)
+        if (tid == 0) sh[256] = a;
     }
-    const double r = sh[0];
+    __syncthreads();
+    const double r = sh[256];
     __syncthreads();
     return r;
 }
@@ -318,24 +323,29 @@ __device__ __forceinline__ unsigned long long block_reduce_sum_u64(unsigned long
     const int tid = threadIdx.x;
     sh[tid] = v;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] += sh[tid + s];
-        __syncthreads();
+    if (tid < 64) {
+        unsigned long long a = (sh[tid] + sh[tid + 128]) + (sh[tid + 64] + sh[tid + 192]);
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) a += __shfl_down(a, s, 64);
+        if (tid == 0) sh[256] = a;
     }
-    const unsigned long long r = sh[0];
+    __syncthreads();
+    const unsigned long long r = sh[256];
     __syncthreads();
     return r;
 }
 
-// largest bin b with edges[b] <= p (the caller has checked p >= edges[0]): hr_tables.cpp ebur128_bin_edges
-__device__ __forceinline__ int ebu_bin_from_edges(const double *__restrict__ edges, double p)
+// largest bin b with edges[b] <= p in table `table` of ebu_edges (hr_tables.cpp ebur128_bin_edges: 0 = the bins themselves --
+// the caller has checked p >= edges[0] --, 1 / 2 = the first bin of the -10 LU / -20 LU relative gate).  The edges decide; the
+// device logarithm only says where to look (a bisection is thirteen dependent loads, this is two or three).
+__device__ __forceinline__ int ebu_bin_from_edges(const double *__restrict__ ebu_edges, int table, double p)
 {
-    int lo = 0, hi = kEbuBins;
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (p >= edges[mid]) lo = mid; else hi = mid;
-    }
-    return lo;
+    const double *__restrict__ edges = ebu_edges + table * kEbuBins;
+    const double e = ((10.0 * log10(p) - 0.691) + 70.0 - 10.0 * table) * 100.0;
+    int b = !(e >= 0.0) ? 0 : e > static_cast<double>(kEbuBins - 1) ? kEbuBins - 1 : static_cast<int>(e);
+    while (b > 0 && p < edges[b]) b--;
+    while (b + 1 < kEbuBins && p >= edges[b + 1]) b++;
+    return b;
 }
 
 // One count for bin `bin` (a negative bin: none) into a workgroup's histogram.  Lanes of a wave that hit the same bin are
@@ -358,37 +368,35 @@ __device__ __forceinline__ void hist_add_wave(uint32_t *hg, int bin)
     if (pending) atomicAdd(&hg[bin], 1u);
 }
 
-__global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
-                                                    int gate_mode, const double *__restrict__ hop_sums,
-                                                    const double *__restrict__ ln_bounds,
-                                                    const double *__restrict__ ebu_edges,
-                                                    double *__restrict__ block_powers,
-                                                    uint32_t *__restrict__ hist, GatePart *__restrict__ parts)
-{
-    // The chunk's histogram is built in LDS and joins the track's afterwards, one atomic per bin the chunk touched: every
-    // increment of a bin in global memory is a read-modify-write at the L2, and the 176 chunks of a steady 10-hour stream
-    // all want the same two or three bins (round 3: 1.15 ms of a 5.5 ms call, profiles/r3_config5_kernel_stats.md).
-    __shared__ uint32_t hh[kEbuBins];
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
-    const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first block of the chunk
-    const TrackDesc &t = tracks[it.track];
-    const int C = t.ch;
-    uint32_t *hg = hist + static_cast<size_t>(it.track) * kEbuBins;  // zeroed by the host before the launch
-    const int nbins = gate_mode == 2 ? kLnBins : gate_mode == 0 ? kEbuBins : 0;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
-    __syncthreads();
+// The gating passes below are written as device functions over ONE workgroup's LDS histogram, so that the chunked kernels (long
+// tracks and streams: one workgroup per chunk of kGateChunk blocks, histograms joined in global memory) and k_gate_small (short
+// tracks: one workgroup does all of a track's gating, nothing in global memory but the block powers) run the same arithmetic in
+// the same order.  PAD: the histogram is stored with one padding slot per 32 bins (k_range_final's layout: its threads walk 32
+// consecutive bins each, starting in different banks).
+template <bool PAD>
+__device__ __forceinline__ int hslot(int i) { return PAD ? i + (i >> 5) : i; }
+constexpr int kHistLds = kEbuBins + kEbuBins / 32 + 1;  // slots of a padded histogram
 
+struct BlockSums { double sum_kept; unsigned long long n_kept; };
+
+// blocks [first, jj_end) of track t: block powers (written to block_powers), absolute gate, counts into hh (zeroed by the
+// caller, who also synchronises afterwards); every thread returns the chunk's kept sum and count
+template <bool PAD>
+__device__ __forceinline__ BlockSums block_hist_chunk(const TrackDesc &t, uint64_t first, uint64_t jj_end, int gate_mode,
+                                                      const double *__restrict__ hop_sums, const double *__restrict__ ln_bounds,
+                                                      const double *__restrict__ ebu_edges, double *__restrict__ block_powers,
+                                                      uint32_t *hh, double *shd, unsigned long long *shu)
+{
+    const int C = t.ch;
     const double bins = gate_mode == 2 ? static_cast<double>(4 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
                                        : static_cast<double>(static_cast<uint64_t>(t.fs) * 4 / 10);
-    const double abs_exact = exp10((-70.0 + 0.691) / 10.0);  // only for HR_GATE_EXACT
+    const double abs_exact = gate_mode == 1 ? exp10((-70.0 + 0.691) / 10.0) : 0.0;  // only for HR_GATE_EXACT
     double sum_kept = 0.0;
     unsigned long long n_kept = 0;
     const double *H = hop_sums + t.hop_base + kPreHop * C;
-    const uint64_t jj_end = it.first + kGateChunk < t.n_blocks ? it.first + kGateChunk : t.n_blocks;
     // (every lane of the workgroup runs every trip of the loop -- lanes past the chunk's end with nothing to add -- so that
     // the wave-wide combination of the histogram counts sees whole waves)
-    for (uint64_t j0 = it.first; j0 < jj_end; j0 += blockDim.x) {
+    for (uint64_t j0 = first; j0 < jj_end; j0 += blockDim.x) {
         const uint64_t jj = j0 + threadIdx.x;
         int bin = -1;
         if (jj < jj_end) {
@@ -404,7 +412,7 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
             if (gate_mode == 0) {
                 // loud = -0.691 + 10 log10(power) >= -70 and its bin, decided on the power itself (ebur128_bin_edges)
                 if (power >= ebu_edges[0]) {
-                    bin = ebu_bin_from_edges(ebu_edges, power);
+                    bin = hslot<PAD>(ebu_bin_from_edges(ebu_edges, 0, power));
                     sum_kept += power;
                     n_kept++;
                 }
@@ -415,7 +423,7 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
                         const int mid = (lo + hi) / 2;
                         if (power >= ln_bounds[mid]) lo = mid; else hi = mid;
                     } while (hi - lo != 1);
-                    bin = lo;
+                    bin = hslot<PAD>(lo);
                     sum_kept += power;
                     n_kept++;
                 }
@@ -425,15 +433,40 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
         }
         if (gate_mode != 1) hist_add_wave(hh, bin);
     }
+    BlockSums r;
+    r.sum_kept = block_reduce_sum(sum_kept, shd);
+    r.n_kept = block_reduce_sum_u64(n_kept, shu);
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
+                                                    int gate_mode, const double *__restrict__ hop_sums,
+                                                    const double *__restrict__ ln_bounds,
+                                                    const double *__restrict__ ebu_edges,
+                                                    double *__restrict__ block_powers,
+                                                    uint32_t *__restrict__ hist, GatePart *__restrict__ parts)
+{
+    // The chunk's histogram is built in LDS and joins the track's afterwards, one atomic per bin the chunk touched: every
+    // increment of a bin in global memory is a read-modify-write at the L2, and the 176 chunks of a steady 10-hour stream
+    // all want the same two or three bins (round 3: 1.15 ms of a 5.5 ms call, profiles/r3_config5_kernel_stats.md).
+    __shared__ uint32_t hh[kEbuBins];
+    __shared__ double shd[257];
+    __shared__ unsigned long long shu[257];
+    const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first block of the chunk
+    const TrackDesc &t = tracks[it.track];
+    uint32_t *hg = hist + static_cast<size_t>(it.track) * kEbuBins;  // zeroed by the host before the launch
+    const int nbins = gate_mode == 2 ? kLnBins : gate_mode == 0 ? kEbuBins : 0;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
     __syncthreads();
+    const uint64_t jj_end = it.first + kGateChunk < t.n_blocks ? it.first + kGateChunk : t.n_blocks;
+    const BlockSums bs = block_hist_chunk<false>(t, it.first, jj_end, gate_mode, hop_sums, ln_bounds, ebu_edges, block_powers, hh, shd, shu);
+    // (the reductions inside end with a barrier: every count is in hh)
     for (int i = threadIdx.x; i < nbins; i += blockDim.x)
         if (hh[i]) atomicAdd(&hg[i], hh[i]);
-    const double sk = block_reduce_sum(sum_kept, shd);
-    const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
     if (threadIdx.x == 0) {
         GatePart &p = parts[t.part_base + it.pad];
-        p.sum_kept = sk;
-        p.n_kept = nk;
+        p.sum_kept = bs.sum_kept;
+        p.n_kept = bs.n_kept;
     }
 }
 
@@ -441,49 +474,28 @@ __global__ void __launch_bounds__(256) k_block_hist(const TrackDesc *__restrict_
 // K2b pass 2: relative gate + gated mean.  One workgroup per track; `outs` carries sum_kept/n_kept
 // (of this track, or all-reduced over shards) and `hist` the (reduced) histogram.
 // ---------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict__ tracks, int gate_mode,
-                                                    const double *__restrict__ block_powers,
-                                                    const uint32_t *__restrict__ hist,
-                                                    const double *__restrict__ ebu_energy,
-                                                    const double *__restrict__ ebu_edges,
-                                                    const double *__restrict__ ln_energy,
-                                                    const double *__restrict__ ln_bounds,
-                                                    const GatePart *__restrict__ parts, int reduce_only,
-                                                    TrackOut *__restrict__ outs)
+// the relative gate and the gated mean of one track from its kept sum / count and its complete histogram hg (global, or the
+// workgroup's LDS); thread 0 writes the results
+template <bool PAD>
+__device__ __forceinline__ void gate_final_track(const TrackDesc &t, int gate_mode, const double *__restrict__ block_powers,
+                                                 const uint32_t *hg, const double *__restrict__ ebu_energy,
+                                                 const double *__restrict__ ebu_edges, const double *__restrict__ ln_energy,
+                                                 const double *__restrict__ ln_bounds, double sum_kept, unsigned long long n_kept,
+                                                 TrackOut &o, double *shd, unsigned long long *shu)
 {
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
-    const TrackDesc &t = tracks[blockIdx.x];
-    TrackOut &o = outs[blockIdx.x];
-    const uint32_t *hg = hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
-    // the chunks' partial sums, in chunk order (n_parts == 0: `outs` already carries sums reduced over shards)
-    if (t.n_parts) {
-        if (threadIdx.x == 0) {
-            double sk = 0.0;
-            unsigned long long nk = 0;
-            for (uint32_t c = 0; c < t.n_parts; c++) { sk += parts[t.part_base + c].sum_kept; nk += parts[t.part_base + c].n_kept; }
-            o.sum_kept = sk;
-            o.n_kept = nk;
-            o.n_blocks = t.n_blocks;
-            o.mean_energy = 0;
-            o.rel_energy = 0;
-            o.n_gated_final = 0;
-        }
-        __syncthreads();
-    }
-    if (reduce_only) return;
-    const unsigned long long n_kept = o.n_kept;
     if (n_kept == 0) return;  // uniform across the block
-
     if (gate_mode == 0) {
-        double rt = o.sum_kept / static_cast<double>(n_kept);
+        double rt = sum_kept / static_cast<double>(n_kept);
         if (!rt) rt = 1e-12;
         // first bin of the relative gate, (int)(((-0.691 + 10 log10(rt)) - 10 + 70) * 100) clipped: table 1 of the edges
-        const int gp = ebu_bin_from_edges(ebu_edges + kEbuBins, rt);
+        const int gp = ebu_bin_from_edges(ebu_edges, 1, rt);
         double isum = 0;
         unsigned long long nint = 0;
         for (int i = gp + threadIdx.x; i < kEbuBins; i += blockDim.x) {
-            const unsigned cnt = hg[i];
+            // (an empty bin adds + 0.0: skipping it leaves the sum's bits alone and saves the load of its energy -- all but a few
+            // dozen bins of a track are empty, and the loads were what a workgroup of k_gate_small spent its time waiting for)
+            const unsigned cnt = hg[hslot<PAD>(i)];
+            if (cnt == 0) continue;
             nint += cnt;
             isum += static_cast<double>(cnt) * ebu_energy[i];
         }
@@ -498,7 +510,8 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
         double gs = 0;
         unsigned long long above = 0;
         for (int i = threadIdx.x; i < kLnBins; i += blockDim.x) {
-            const unsigned cnt = hg[i];
+            const unsigned cnt = hg[hslot<PAD>(i)];
+            if (cnt == 0) continue;
             above += cnt;
             gs += static_cast<double>(cnt) * ln_energy[i];
         }
@@ -521,7 +534,8 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
         gs = 0;
         above = 0;
         for (int i = start + threadIdx.x; i < kLnBins; i += blockDim.x) {
-            const unsigned cnt = hg[i];
+            const unsigned cnt = hg[hslot<PAD>(i)];
+            if (cnt == 0) continue;
             above += cnt;
             gs += static_cast<double>(cnt) * ln_energy[i];
         }
@@ -534,7 +548,7 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
         }
     } else {
         const double abs_exact = exp10((-70.0 + 0.691) / 10.0);
-        const double mean1 = o.sum_kept / static_cast<double>(n_kept);
+        const double mean1 = sum_kept / static_cast<double>(n_kept);
         const double rel = 0.1 * mean1;
         double s2 = 0;
         unsigned long long n2 = 0;
@@ -553,6 +567,42 @@ __global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict_
     }
 }
 
+// list: the tracks this launch is for (their indices in WorkItem::track), or nullptr for tracks 0 .. gridDim.x - 1
+__global__ void __launch_bounds__(256) k_gate_final(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ list, int gate_mode,
+                                                    const double *__restrict__ block_powers,
+                                                    const uint32_t *__restrict__ hist,
+                                                    const double *__restrict__ ebu_energy,
+                                                    const double *__restrict__ ebu_edges,
+                                                    const double *__restrict__ ln_energy,
+                                                    const double *__restrict__ ln_bounds,
+                                                    const GatePart *__restrict__ parts, int reduce_only,
+                                                    TrackOut *__restrict__ outs)
+{
+    __shared__ double shd[257];
+    __shared__ unsigned long long shu[257];
+    const uint32_t ti = list ? list[blockIdx.x].track : blockIdx.x;
+    const TrackDesc &t = tracks[ti];
+    TrackOut &o = outs[ti];
+    const uint32_t *hg = hist + static_cast<size_t>(ti) * kEbuBins;
+    // the chunks' partial sums, in chunk order (n_parts == 0: `outs` already carries sums reduced over shards)
+    if (t.n_parts) {
+        if (threadIdx.x == 0) {
+            double sk = 0.0;
+            unsigned long long nk = 0;
+            for (uint32_t c = 0; c < t.n_parts; c++) { sk += parts[t.part_base + c].sum_kept; nk += parts[t.part_base + c].n_kept; }
+            o.sum_kept = sk;
+            o.n_kept = nk;
+            o.n_blocks = t.n_blocks;
+            o.mean_energy = 0;
+            o.rel_energy = 0;
+            o.n_gated_final = 0;
+        }
+        __syncthreads();
+    }
+    if (reduce_only) return;
+    gate_final_track<false>(t, gate_mode, block_powers, hg, ebu_energy, ebu_edges, ln_energy, ln_bounds, o.sum_kept, o.n_kept, o, shd, shu);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Loudness range + maximum momentary / short-term power.  One workgroup per (whole) track; the short-term
 // histogram lives in LDS.  gate modes 0, 1: f_ebur128.c (i3000 histogram, gate_update with -20 LU, its 10 % / 95 %
@@ -563,32 +613,30 @@ __device__ __forceinline__ double block_reduce_max(double v, double *sh)
     const int tid = threadIdx.x;
     sh[tid] = v;
     __syncthreads();
-    for (int s = blockDim.x / 2; s > 0; s >>= 1) {
-        if (tid < s) sh[tid] = sh[tid + s] > sh[tid] ? sh[tid + s] : sh[tid];
-        __syncthreads();
+    if (tid < 64) {
+        double a = fmax(fmax(sh[tid], sh[tid + 128]), fmax(sh[tid + 64], sh[tid + 192]));
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) a = fmax(a, __shfl_down(a, s, 64));
+        if (tid == 0) sh[256] = a;
     }
-    const double r = sh[0];
+    __syncthreads();
+    const double r = sh[256];
     __syncthreads();
     return r;
 }
 
-__global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
-                                                     int gate_mode, const double *__restrict__ hop_sums,
-                                                     const double *__restrict__ block_powers,
-                                                     const double *__restrict__ ln_bounds,
-                                                     const double *__restrict__ ebu_edges, uint32_t *__restrict__ st_hist,
-                                                     GatePart *__restrict__ parts)
+struct RangeSums { double sum_kept, max_s, max_m; unsigned long long n_kept; };
+
+// short-term windows and blocks [first, first + kGateChunk) of track t: counts into hh (zeroed by the caller), every thread
+// returns the chunk's sums and maxima
+template <bool PAD>
+__device__ __forceinline__ RangeSums range_stats_chunk(const TrackDesc &t, uint64_t first, int gate_mode,
+                                                       const double *__restrict__ hop_sums, const double *__restrict__ block_powers,
+                                                       const double *__restrict__ ln_bounds, const double *__restrict__ ebu_edges,
+                                                       uint32_t *hh, double *shd, unsigned long long *shu)
 {
-    __shared__ uint32_t hh[kEbuBins];
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
-    const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first window / block of the chunk
-    const TrackDesc &t = tracks[it.track];
     const int C = t.ch;
     const bool ln = gate_mode == 2;
-    const int nbins = ln ? kLnBins : kEbuBins;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
-    __syncthreads();
     // windows are counted by their LAST hop: a shard owns those that end in it, i.e. start at -st_pre or later
     const uint64_t n_s = t.n_hops + t.st_pre >= 30 ? t.n_hops + t.st_pre - 29 : 0;
     const double bins = ln ? static_cast<double>(30 * ((static_cast<uint64_t>(t.fs) + 5) / 10))
@@ -596,8 +644,8 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
     const double *H = hop_sums + t.hop_base + kPreHop * C;
     double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
     unsigned long long n_kept = 0;
-    const uint64_t j_end = it.first + kGateChunk < n_s ? it.first + kGateChunk : n_s;
-    for (uint64_t jw = it.first + threadIdx.x; jw < j_end; jw += blockDim.x) {
+    const uint64_t j_end = first + kGateChunk < n_s ? first + kGateChunk : n_s;
+    for (uint64_t jw = first + threadIdx.x; jw < j_end; jw += blockDim.x) {
         const int64_t j = static_cast<int64_t>(jw) - t.st_pre;  // first hop of the window, relative to this shard
         double power = ln ? 0.0 : 1e-12;
         for (int c = 0; c < C; c++) {
@@ -610,7 +658,7 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
         max_s = power > max_s ? power : max_s;
         if (!ln) {
             if (power >= ebu_edges[0]) {  // (as in k_block_hist)
-                atomicAdd(&hh[ebu_bin_from_edges(ebu_edges, power)], 1u);
+                atomicAdd(&hh[hslot<PAD>(ebu_bin_from_edges(ebu_edges, 0, power))], 1u);
                 sum_kept += power;
                 n_kept++;
             }
@@ -620,62 +668,65 @@ __global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict
                 const int mid = (lo + hi) / 2;
                 if (power >= ln_bounds[mid]) lo = mid; else hi = mid;
             } while (hi - lo != 1);
-            atomicAdd(&hh[lo], 1u);
+            atomicAdd(&hh[hslot<PAD>(lo)], 1u);
         }
     }
-    const uint64_t b_end = it.first + kGateChunk < t.n_blocks ? it.first + kGateChunk : t.n_blocks;
-    for (uint64_t jj = it.first + threadIdx.x; jj < b_end; jj += blockDim.x) {
+    const uint64_t b_end = first + kGateChunk < t.n_blocks ? first + kGateChunk : t.n_blocks;
+    for (uint64_t jj = first + threadIdx.x; jj < b_end; jj += blockDim.x) {
         const double p = block_powers[t.blk_base + jj];
         max_m = p > max_m ? p : max_m;
     }
-    max_s = block_reduce_max(max_s, shd);
-    max_m = block_reduce_max(max_m, shd);
-    const double sk = block_reduce_sum(sum_kept, shd);
-    const unsigned long long nk = block_reduce_sum_u64(n_kept, shu);
+    RangeSums r;
+    r.max_s = block_reduce_max(max_s, shd);
+    r.max_m = block_reduce_max(max_m, shd);
+    r.sum_kept = block_reduce_sum(sum_kept, shd);
+    r.n_kept = block_reduce_sum_u64(n_kept, shu);
+    return r;
+}
+
+__global__ void __launch_bounds__(256) k_range_stats(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ items,
+                                                     int gate_mode, const double *__restrict__ hop_sums,
+                                                     const double *__restrict__ block_powers,
+                                                     const double *__restrict__ ln_bounds,
+                                                     const double *__restrict__ ebu_edges, uint32_t *__restrict__ st_hist,
+                                                     GatePart *__restrict__ parts)
+{
+    __shared__ uint32_t hh[kEbuBins];
+    __shared__ double shd[257];
+    __shared__ unsigned long long shu[257];
+    const WorkItem it = items[blockIdx.x];  // track, chunk index (pad), first window / block of the chunk
+    const TrackDesc &t = tracks[it.track];
+    const int nbins = gate_mode == 2 ? kLnBins : kEbuBins;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) hh[i] = 0;
+    __syncthreads();
+    const RangeSums rs = range_stats_chunk<false>(t, it.first, gate_mode, hop_sums, block_powers, ln_bounds, ebu_edges, hh, shd, shu);
     // the chunk's histogram joins the track's (zeroed by the host before the launch)
     uint32_t *hg = st_hist + static_cast<size_t>(it.track) * kEbuBins;
     for (int i = threadIdx.x; i < nbins; i += blockDim.x)
         if (hh[i]) atomicAdd(&hg[i], hh[i]);
     if (threadIdx.x == 0) {
         GatePart &p = parts[t.part_base + it.pad];
-        p.st_sum_kept = sk;
-        p.st_n_kept = nk;
-        p.max_s_power = max_s;
-        p.max_m_power = max_m;
+        p.st_sum_kept = rs.sum_kept;
+        p.st_n_kept = rs.n_kept;
+        p.max_s_power = rs.max_s;
+        p.max_m_power = rs.max_m;
     }
 }
 
-// the track's loudness range from its complete short-term histogram; one workgroup per track
-__global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict__ tracks, int gate_mode,
-                                                     const uint32_t *__restrict__ st_hist, const GatePart *__restrict__ parts,
-                                                     const double *__restrict__ ln_bounds,
-                                                     const double *__restrict__ ln_energy,
-                                                     const double *__restrict__ ebu_edges, TrackOut *__restrict__ outs)
+// the track's loudness range from its complete short-term histogram lh (LDS, padded: hslot<true>) and the sums / maxima of its
+// chunks; thread 0 writes the results.  lo_bin / hi_bin: two ints in LDS.
+__device__ __forceinline__ void range_final_track(const TrackDesc &t, int gate_mode, const uint32_t *lh, double sum_kept,
+                                                  unsigned long long n_kept, double max_s, double max_m,
+                                                  const double *__restrict__ ln_bounds, const double *__restrict__ ln_energy,
+                                                  const double *__restrict__ ebu_edges, TrackOut &o, double *shd,
+                                                  unsigned long long *shu, int *lo_bin_p, int *hi_bin_p)
 {
-    __shared__ double shd[256];
-    __shared__ unsigned long long shu[256];
-    __shared__ int lo_bin, hi_bin;
-    const TrackDesc &t = tracks[blockIdx.x];
-    TrackOut &o = outs[blockIdx.x];
+    int &lo_bin = *lo_bin_p, &hi_bin = *hi_bin_p;
     const bool ln = gate_mode == 2;
     const int nbins = ln ? kLnBins : kEbuBins;
-    // the track's histogram, read once, coalesced, into LDS; every thread then walks its own 32 consecutive bins there
-    // (one padding slot per 32 bins: the threads' walks start in different banks)
-    __shared__ uint32_t lh[kEbuBins + kEbuBins / 32 + 1];
-    const uint32_t *hg = st_hist + static_cast<size_t>(blockIdx.x) * kEbuBins;
-    for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i + (i >> 5)] = hg[i];
     auto hh = [&](int i) { return lh[i + (i >> 5)]; };
     if (threadIdx.x == 0) { lo_bin = nbins; hi_bin = ln ? nbins : -1; }
     __syncthreads();
-    double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
-    unsigned long long n_kept = 0;
-    for (uint32_t c = 0; c < t.n_parts; c++) {  // chunk order, every thread the same
-        const GatePart &p = parts[t.part_base + c];
-        sum_kept += p.st_sum_kept;
-        n_kept += p.st_n_kept;
-        max_s = p.max_s_power > max_s ? p.max_s_power : max_s;
-        max_m = p.max_m_power > max_m ? p.max_m_power : max_m;
-    }
     // first bin of the range statistics and the mean power the relative gate derives from
     int first = 0;
     double rel_energy = 0.0;
@@ -688,12 +739,13 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
             double rt = sum_kept / static_cast<double>(n_kept);
             if (!rt) rt = 1e-12;
             rel_energy = rt;
-            first = ebu_bin_from_edges(ebu_edges + 2 * kEbuBins, rt);  // the -20 LU gate's first bin (table 2 of the edges)
+            first = ebu_bin_from_edges(ebu_edges, 2, rt);  // the -20 LU gate's first bin (table 2 of the edges)
         }
     } else {
         double gs = 0;
         unsigned long long cnt = 0;
-        for (int i = c0; i < c1; i++) { cnt += hh(i); gs += static_cast<double>(hh(i)) * ln_energy[i]; }
+        for (int i = c0; i < c1; i++)
+            if (hh(i)) { cnt += hh(i); gs += static_cast<double>(hh(i)) * ln_energy[i]; }
         const double g1 = block_reduce_sum(gs, shd);
         const unsigned long long a1 = block_reduce_sum_u64(cnt, shu);
         any = a1 != 0;
@@ -760,16 +812,118 @@ __global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict
     }
 }
 
+// the track's loudness range from its complete short-term histogram; one workgroup per track (list: as for k_gate_final)
+__global__ void __launch_bounds__(256) k_range_final(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ list, int gate_mode,
+                                                     const uint32_t *__restrict__ st_hist, const GatePart *__restrict__ parts,
+                                                     const double *__restrict__ ln_bounds,
+                                                     const double *__restrict__ ln_energy,
+                                                     const double *__restrict__ ebu_edges, TrackOut *__restrict__ outs)
+{
+    __shared__ double shd[257];
+    __shared__ unsigned long long shu[257];
+    __shared__ int lo_bin, hi_bin;
+    const uint32_t ti = list ? list[blockIdx.x].track : blockIdx.x;
+    const TrackDesc &t = tracks[ti];
+    const int nbins = gate_mode == 2 ? kLnBins : kEbuBins;
+    // the track's histogram, read once, coalesced, into LDS; every thread then walks its own 32 consecutive bins there
+    // (one padding slot per 32 bins: the threads' walks start in different banks)
+    __shared__ uint32_t lh[kHistLds];
+    const uint32_t *hg = st_hist + static_cast<size_t>(ti) * kEbuBins;
+    for (int i = threadIdx.x; i < nbins; i += blockDim.x) lh[i + (i >> 5)] = hg[i];
+    double sum_kept = 0.0, max_s = 0.0, max_m = 0.0;
+    unsigned long long n_kept = 0;
+    for (uint32_t c = 0; c < t.n_parts; c++) {  // chunk order, every thread the same
+        const GatePart &p = parts[t.part_base + c];
+        sum_kept += p.st_sum_kept;
+        n_kept += p.st_n_kept;
+        max_s = p.max_s_power > max_s ? p.max_s_power : max_s;
+        max_m = p.max_m_power > max_m ? p.max_m_power : max_m;
+    }
+    range_final_track(t, gate_mode, lh, sum_kept, n_kept, max_s, max_m, ln_bounds, ln_energy, ebu_edges, outs[ti], shd, shu, &lo_bin, &hi_bin);
+}
+
+// ---------------------------------------------------------------------------------------------
+// All of a SHORT track's gating in one workgroup (tracks of at most kGateSmallParts chunks: 27 minutes): block powers and
+// gating histogram, relative gate and gated mean, short-term histogram, loudness range -- what k_block_hist, k_gate_final,
+// k_range_stats and k_range_final do for a long track, chunk by chunk in the same order with the same reductions (same result
+// bits), but with the two histograms in LDS, one after the other.  A launch of 10 000 ten-second clips otherwise zeroes, fills
+// and re-reads 640 MB of histograms in global memory for 97 blocks per track (round 3: 0.83 of a 14.8 ms step -> 0.1 ms).
+// Mirrors the many-small-files case of the reference (src/cli.rs:403-435: one ffmpeg run per file, however short).
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_gate_small(const TrackDesc *__restrict__ tracks, const WorkItem *__restrict__ list, int gate_mode,
+                                                    const double *__restrict__ hop_sums, double *__restrict__ block_powers,
+                                                    const double *__restrict__ ebu_energy, const double *__restrict__ ebu_edges,
+                                                    const double *__restrict__ ln_energy, const double *__restrict__ ln_bounds,
+                                                    TrackOut *__restrict__ outs)
+{
+    __shared__ uint32_t lh[kHistLds];
+    __shared__ double shd[257];
+    __shared__ unsigned long long shu[257];
+    __shared__ int lo_bin, hi_bin;
+    const uint32_t ti = list[blockIdx.x].track;
+    const TrackDesc &t = tracks[ti];
+    TrackOut &o = outs[ti];
+    for (int i = threadIdx.x; i < kHistLds; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    // pass 1: the chunks in order, their sums added in chunk order (what k_gate_final's thread 0 does with the GatePart records)
+    double sk = 0.0;
+    unsigned long long nk = 0;
+    for (uint32_t c = 0; c < t.n_parts; c++) {
+        const uint64_t first = static_cast<uint64_t>(c) * kGateChunk;
+        const uint64_t jj_end = first + kGateChunk < t.n_blocks ? first + kGateChunk : t.n_blocks;
+        const BlockSums bs = block_hist_chunk<true>(t, first, jj_end, gate_mode, hop_sums, ln_bounds, ebu_edges, block_powers, lh, shd, shu);
+        sk += bs.sum_kept;
+        nk += bs.n_kept;
+    }
+    if (threadIdx.x == 0) {
+        o.sum_kept = sk;
+        o.n_kept = nk;
+        o.n_blocks = t.n_blocks;
+        o.mean_energy = 0;
+        o.rel_energy = 0;
+        o.n_gated_final = 0;
+    }
+    // (block powers written above are read below by other threads of this workgroup: HR_GATE_EXACT's second pass, the maxima)
+    __threadfence_block();
+    __syncthreads();
+    gate_final_track<true>(t, gate_mode, block_powers, lh, ebu_energy, ebu_edges, ln_energy, ln_bounds, sk, nk, o, shd, shu);
+    __syncthreads();
+    // pass 2: the short-term histogram takes the gating histogram's place
+    for (int i = threadIdx.x; i < kHistLds; i += blockDim.x) lh[i] = 0;
+    __syncthreads();
+    double st_sum = 0.0, max_s = 0.0, max_m = 0.0;
+    unsigned long long st_n = 0;
+    for (uint32_t c = 0; c < t.n_parts; c++) {
+        const RangeSums rs = range_stats_chunk<true>(t, static_cast<uint64_t>(c) * kGateChunk, gate_mode, hop_sums, block_powers, ln_bounds,
+                                                     ebu_edges, lh, shd, shu);
+        st_sum += rs.sum_kept;
+        st_n += rs.n_kept;
+        max_s = rs.max_s > max_s ? rs.max_s : max_s;
+        max_m = rs.max_m > max_m ? rs.max_m : max_m;
+    }
+    range_final_track(t, gate_mode, lh, st_sum, st_n, max_s, max_m, ln_bounds, ln_energy, ebu_edges, o, shd, shu, &lo_bin, &hi_bin);
+}
+
+void launch_gate_small(const TrackDesc *tracks, const WorkItem *list, uint32_t n_list, int gate_mode, const double *hop_sums,
+                       double *block_powers, const double *ebu_energy, const double *ebu_edges, const double *ln_energy,
+                       const double *ln_bounds, TrackOut *outs, hipStream_t st)
+{
+    if (!n_list) return;
+    hipLaunchKernelGGL(k_gate_small, dim3(n_list), dim3(256), 0, st, tracks, list, gate_mode, hop_sums, block_powers, ebu_energy,
+                       ebu_edges, ln_energy, ln_bounds, outs);
+}
+
 void launch_range_stats(const TrackDesc *tracks, uint32_t n_tracks, const WorkItem *items, uint32_t n_items, int gate_mode,
                         const double *hop_sums, const double *block_powers, const double *ln_bounds, const double *ln_energy,
-                        const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st)
+                        const double *ebu_edges, uint32_t *st_hist, GatePart *parts, bool finalize, TrackOut *outs, hipStream_t st,
+                        const WorkItem *list)
 {
     if (!n_tracks) return;
     if (n_items)
         hipLaunchKernelGGL(k_range_stats, dim3(n_items), dim3(256), 0, st, tracks, items, gate_mode, hop_sums, block_powers,
                            ln_bounds, ebu_edges, st_hist, parts);
     if (finalize)
-        hipLaunchKernelGGL(k_range_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, st_hist, parts, ln_bounds, ln_energy,
+        hipLaunchKernelGGL(k_range_final, dim3(n_tracks), dim3(256), 0, st, tracks, list, gate_mode, st_hist, parts, ln_bounds, ln_energy,
                        ebu_edges, outs);
 }
 
@@ -1081,10 +1235,11 @@ void launch_block_hist(const TrackDesc *tracks, const WorkItem *items, uint32_t 
 
 void launch_gate_final(const TrackDesc *tracks, uint32_t n_tracks, int gate_mode, const double *block_powers,
                        const uint32_t *hist, const double *ebu_energy, const double *ebu_edges, const double *ln_energy,
-                       const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st)
+                       const double *ln_bounds, const GatePart *parts, bool reduce_only, TrackOut *outs, hipStream_t st,
+                       const WorkItem *list)
 {
     if (!n_tracks) return;
-    hipLaunchKernelGGL(k_gate_final, dim3(n_tracks), dim3(256), 0, st, tracks, gate_mode, block_powers, hist,
+    hipLaunchKernelGGL(k_gate_final, dim3(n_tracks), dim3(256), 0, st, tracks, list, gate_mode, block_powers, hist,
                        ebu_energy, ebu_edges, ln_energy, ln_bounds, parts, reduce_only ? 1 : 0, outs);
 }
 
