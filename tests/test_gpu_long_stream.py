@@ -108,3 +108,31 @@ def test_many_gating_chunks_whole_and_sharded(oracle, stream, gate):
         # order: per shard, then over shards)
         assert abs(got["integrated_lufs"] - whole["integrated_lufs"]) < 1e-9
         assert got["n_gated"] == whole["n_gated"]
+
+
+@pytest.mark.parametrize("gate", ["ebur128", "loudnorm", "exact"])
+def test_short_and_long_tracks_in_one_launch(oracle, stream, gate):
+    """One launch that holds tracks of one gating chunk, of several (k_gate_small: one workgroup gates the whole track, the
+    histograms in LDS, the chunks' sums added in chunk order) and of more than kGateSmallParts = 8 (the chunked kernels
+    through the histograms in global memory, told by a list which tracks are theirs): every one against the oracle, and
+    the same bits as when it is analysed alone."""
+    cuts = [(0, 700), (1000, 1000 + 5000), (0, stream.shape[0] // HOP), (9000, 9000 + 2048 * 8), (20000, 20000 + 31), (30000, 30000 + 2048 * 8 + 4)]
+    specs, pcms = [], []
+    for a, b in cuts:
+        pcm = stream[a * HOP: b * HOP + 57] if b * HOP + 57 <= stream.shape[0] else stream[a * HOP:]
+        pcms.append(pcm)
+        specs.append(hr.TrackSpec(pcm, FS))
+    with hr.Meter(device=0, gate_mode=GATES[gate], tp_mode=hr.TP_SAMPLE) as m:
+        got = m.analyze_batch(specs)
+        for g, pcm in zip(got, pcms):
+            ref = oracle.measure(pcm, FS, gate_mode=GATES[gate], tp_mode=2)
+            rng_ref = oracle.range_stats(pcm, FS, GATES[gate])
+            assert g["status"] == 0
+            assert g["n_blocks"] == ref["n_blocks"] and g["n_gated"] == ref["n_gated"]
+            assert abs(g["integrated_lufs"] - ref["integrated_lufs"]) < 1e-6
+            assert g["peak_per_ch"] == ref["peak_per_ch"]
+            for k_got, k_ref in RANGE_KEYS:
+                assert close(g[k_got], rng_ref[k_ref], 1e-6), (k_got, g[k_got], rng_ref[k_ref])
+            alone = m.analyze(pcm, FS)
+            for k in ("integrated_lufs", "rel_threshold_lufs", "n_gated", "n_blocks", "peak_per_ch") + tuple(k for k, _ in RANGE_KEYS):
+                assert g[k] == alone[k] or (isinstance(g[k], float) and math.isnan(g[k]) and math.isnan(alone[k])), (k, g[k], alone[k])
