@@ -253,14 +253,14 @@ def main():
         kernel_ms = sum(main_ms) / max(len(main_ms), 1)
         achieved = bytes_per_step / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         # HBM bytes per launch of the fused kernel: PMC counters need a profiler pass of their own, so this is the
-        # committed measurement (profiles/r2_fused_hbm_traffic.json, bytes per track) scaled to this launch
+        # committed measurement (profiles/r3_fused_hbm_traffic.json, bytes per track) scaled to this launch
         traffic, traffic_src = None, None
-        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r2_fused_hbm_traffic.json")
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r3_fused_hbm_traffic.json")
         if (os.path.exists(tpath) and args.workload == "config2" and args.pcm_format == "f32" and SECONDS == 180 and not args.ragged
-                and args.tp_mode == "swr192k"):
+                and args.tp_mode == "swr192k" and args.engine == 0):
             with open(tpath) as fh:
                 traffic = json.load(fh)["bytes_per_track"] * n_tracks
-            traffic_src = "profiles/r2_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
+            traffic_src = "profiles/r3_fused_hbm_traffic.json (rocprofv3 --pmc TCC_EA0_RDREQ/WRREQ pass, gfx950 x2 read correction), per track x tracks in the launch"
         line = {
             "metric": "audio-hours analyzed/sec (LUFS+dBTP)", "value": value, "unit": "audio-hours/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -237,11 +237,13 @@ int rate_index(hr_ctx *ctx, uint32_t fs)
     rd.q_n0 = rt->q_n0;
     std::memcpy(rd.q_ab, rt->q_ab, sizeof rd.q_ab);
     void *g = nullptr;
-    HIPCHK(hipMalloc(&g, rt->g.size() * sizeof(double) + 2048));  // the fused kernel's 1 KiB slices read past the end
+    // (the fused kernel's 1 KiB slices read past the end, and the first slice of a row with a shifted piece grid starts up to 14
+    // entries in front of the table: 512 bytes of zeros there)
+    HIPCHK(hipMalloc(&g, rt->g.size() * sizeof(double) + 2048 + 512));
     ctx->rate_allocs.push_back(g);
-    HIPCHK(hipMemset(g, 0, rt->g.size() * sizeof(double) + 2048));
-    HIPCHK(hipMemcpy(g, rt->g.data(), rt->g.size() * sizeof(double), hipMemcpyHostToDevice));
-    rd.g = static_cast<const double *>(g);
+    HIPCHK(hipMemset(g, 0, rt->g.size() * sizeof(double) + 2048 + 512));
+    HIPCHK(hipMemcpy(static_cast<char *>(g) + 512, rt->g.data(), rt->g.size() * sizeof(double), hipMemcpyHostToDevice));
+    rd.g = reinterpret_cast<const double *>(static_cast<const char *>(g) + 512);
     // the interpolation bank of the context's true-peak mode
     const bool bs = ctx->cfg.tp_mode == HR_TP_BS1770;
     const int phases = bs ? rt->bs_phases : rt->swr_phases;
@@ -584,20 +586,77 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                        : ftp[i] ? fused_tp_class(rd.tp_mt, rd.tp_last_rows) + (g.fmts[i] == HR_FMT_S16 ? 8 : g.fmts[i] == HR_FMT_S24 ? 14 : 0) : fsp[i] ? 7 : 6;
         by_class_rate[static_cast<size_t>(mine) * n_rates + g.descs[i].rate_idx].push_back(static_cast<uint32_t>(i));
     }
+    // Line-aligned rows (hr_fused_core.hpp, FusedItem::phi): stereo f32 whose hops do not start on cache lines (44.1 kHz: a hop is
+    // 35 280 bytes) but whose buffer does.  Hops h and h + 8 start at the same offset from the 128-byte grid, so the whole-hop
+    // rows of a track are taken in blocks of 512 hops as eight items of 64 rows, hops 512 b + j + 8 r, whose piece grids start
+    // phi(j) frames early, on a line; what is left of the track behind its last whole block stays as it was.  The four waves of
+    // a workgroup share the coefficient tiles and the carry-table slices, so every phi is a run of its own.
+    // hr_config.engine = 7 keeps all rows as they were (A/B and tests).
+    constexpr uint64_t kAlignedBlock = 512;
+#ifdef HR_EXPERIMENTS  // HR_ALIGN_MODE=1: strided items whose grids are NOT shifted (what the stride alone costs: +4.4 % kernel time)
+    static const int align_mode = std::getenv("HR_ALIGN_MODE") ? std::atoi(std::getenv("HR_ALIGN_MODE")) : 0;
+#else
+    constexpr int align_mode = 0;
+#endif
+    auto phi_of = [&](const TrackDesc &d, uint64_t j) { return align_mode == 1 ? 0u : static_cast<uint32_t>(((j * d.hop * 8ull) % 128) / 8); };
+    // per rate and phi / 2: the tile pattern a grid that starts phi frames before a hop begins with (16 pat0 + phi is a whole
+    // number of input steps); -1: there is none
+    std::vector<int> pat0_tab(n_rates * 8, 0);
+    for (size_t ri = 0; ri < n_rates; ri++) {
+        const RateDev &rd = ctx->rates_h[ri];
+        for (uint32_t q = 0; q < 8; q++) {
+            int found = rd.tp_np <= 1 || rd.swr_step <= 1 ? 0 : -1;
+            for (int p = 0; p < rd.tp_np && found < 0; p++)
+                if ((16ll * p + 2 * q) % rd.swr_step == 0) found = p;
+            pat0_tab[ri * 8 + q] = found;
+        }
+    }
+    // per track: whole blocks of 512 hops that take shifted grids (in front of everything else of the track)
+    std::vector<uint64_t> al_blocks(nt, 0);
+    for (size_t i = 0; i < nt; i++) {
+        const TrackDesc &d = g.descs[i];
+        if (!fkw[i] || fmc[i] || g.fmts[i] != HR_FMT_F32 || d.ch != 2 || ctx->cfg.engine == 7 || ctx->split || (d.hop * 8ull) % 128 == 0 ||
+            (reinterpret_cast<uintptr_t>(d.pcm) & 127))
+            continue;
+        bool ok = true;
+        for (uint64_t j = 0; j < 8 && ok; j++) ok = phi_of(d, j) % 2 == 0 && pat0_tab[d.rate_idx * 8 + phi_of(d, j) / 2] >= 0;
+        const uint64_t limit = sub_from[i] < d.n_hops ? sub_from[i] : d.n_hops - 1;  // (never the track's final row)
+        if (ok) al_blocks[i] = limit / kAlignedBlock;
+    }
     for (int cls = 0; cls < kFusedClasses; cls++) {
         class_off[cls] = fitems.size();
-        for (size_t rp = 0; rp < 2 * n_rates; rp++) {  // (rate, whole-hop rows) then (rate, shorter rows)
-            const size_t ri = rp / 2;
-            const bool shorter = rp % 2 == 1;
+        for (size_t rp = 0; rp < 10 * n_rates; rp++) {  // (rate, whole-hop rows), (rate, shorter rows), (rate, aligned rows of phi = 0, 2 .. 14)
+            const size_t ri = rp / 10;
+            const bool shorter = rp % 10 == 1;
+            const int al_phi = rp % 10 >= 2 ? static_cast<int>(2 * (rp % 10 - 2)) : -1;
             const size_t run_begin = fitems.size();
             for (const uint32_t i : by_class_rate[static_cast<size_t>(cls) * n_rates + ri]) {
                 const TrackDesc &d = g.descs[i];
+                const uint64_t nb = al_blocks[i];
+                if (al_phi >= 0) {
+                    for (uint64_t j = 0; j < 8 && nb; j++) {
+                        if (phi_of(d, j) != static_cast<uint32_t>(al_phi)) continue;
+                        for (uint64_t b = 0; b < nb; b++) {
+                            FusedItem it{};
+                            it.track = i;
+                            it.n_rows = 64;
+                            it.first_hop = b * kAlignedBlock + j;
+                            it.frame0 = it.first_hop * d.hop;
+                            it.row_len = d.hop;
+                            it.row_stride = 8;
+                            it.phi = static_cast<uint16_t>(al_phi);
+                            it.pat0 = static_cast<uint32_t>(pat0_tab[d.rate_idx * 8 + al_phi / 2]);
+                            fitems.push_back(it);
+                        }
+                    }
+                    continue;
+                }
                 // this section's rows: record rows [r0, r1) from frame f0 on, `len` frames each; the track's last section
                 // also holds the rows behind the last hop, and loses the final hop's row when that one stays generic
                 const bool has_sub = sub_from[i] < d.n_hops;
                 uint64_t r0, r1, f0, len;
                 if (!shorter) {
-                    r0 = 0; r1 = sub_from[i]; f0 = 0; len = d.hop;
+                    r0 = nb * kAlignedBlock; r1 = sub_from[i]; f0 = r0 * d.hop; len = d.hop;  // (behind the aligned blocks)
                     if (!has_sub) r1 = r1 - (ffin[i] ? 0 : 1) + tail_rows_of[i];
                 } else {
                     if (!has_sub) continue;
@@ -613,6 +672,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                     it.frame0 = f0 + (r - r0) * len;
                     it.row_len = static_cast<uint32_t>(len);
                     it.last = last_section && ffin[i] && r + 64 >= r1;
+                    it.row_stride = 1;
                     fitems.push_back(it);
                 }
             }
@@ -1272,7 +1332,7 @@ try {
     *out = nullptr;
     hr_config c{};
     if (cfg) c = *cfg;
-    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 6) return HR_ERR_INVALID;
+    if (c.gate_mode < 0 || c.gate_mode > 2 || c.tp_mode < 0 || c.tp_mode > 2 || c.engine < 0 || c.engine > 7) return HR_ERR_INVALID;
     const int n = hr_device_count();
     if (n <= 0) return HR_ERR_NO_DEVICE;
     if (c.device < 0 || c.device >= n) return HR_ERR_INVALID;

@@ -128,6 +128,12 @@ struct FusedItem {
     uint64_t frame0;     // frame at which that row starts
     uint32_t row_len;    // frames per row: a hop, or a whole fraction of one
     uint32_t last;       // the wave's last row is the track's last fused row (TrackDesc::fin_valid)
+    // line-aligned rows (stereo f32 at rates whose hops do not start on cache lines; hr_fused_core.hpp): the item's rows are
+    // hops first_hop, first_hop + row_stride, ... (they share their offset from the 128-byte grid), every row's 16-frame
+    // pieces start phi frames before the row, on a line, and the tile patterns start at pat0.  1, 0, 0: rows as they were.
+    uint16_t row_stride;
+    uint16_t phi;
+    uint32_t pat0;
 };
 
 struct TrackOut {  // what the finalize kernel hands to the host

@@ -378,11 +378,23 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
     // a workgroup step in lock step, so the wave that holds it only waits longer at the barrier, and the wave-uniform branch
     // around every sample's K-weighting cost all waves 6 %: 355 against 378 audio-hours/s on BASELINE configs[3].)
     const uint32_t hop = it.row_len;  // frames per row: a hop, or a whole fraction of one
-    const int T = static_cast<int>((hop + 15) / 16);  // 16-frame pieces per row (the last may be partial)
+    // Line-aligned rows (stereo f32; host: run_measure, FusedItem::phi / row_stride / pat0).  At 44.1 kHz a hop is 35 280 bytes:
+    // the 128-byte pieces of a row that starts at a hop straddle cache lines, every line is requested twice, a step apart, and a
+    // third of the second requests miss the L2 (1.39 x the algorithmic traffic).  Hops h, h + 8, h + 16 ... start at the same
+    // offset from the line grid, so an item may hold 64 such hops (row_stride 8) and start every row's PIECE GRID phi frames
+    // early, on a line: the K-weighting then starts phi frames into piece 0 and ends phi frames later, the carry-table slices
+    // and the q[0..1] hand-over shift by phi, and the tile patterns are the same sequence started at pat0 (a grid that starts
+    // phi frames before a hop looks to the resampler like one that starts 16 pat0 frames after one).  Such items never hold
+    // a track's last row.
+    constexpr bool ALIGNED_OK = !MC && INF == 0;
+    const unsigned phi = ALIGNED_OK ? it.phi : 0u;                // frames between the grid's start and the row's (wave-uniform)
+    const unsigned rstride = ALIGNED_OK ? it.row_stride : 1u;     // hops between the item's rows
+    const uint32_t hopg = hop + phi;                              // frames from the grid's start to the row's end
+    const int T = static_cast<int>((hopg + 15) / 16);  // 16-frame pieces per row (the last may be partial)
     const int n_rows = static_cast<int>(it.n_rows);  // 0: a padding item (computes on row 0, reports nothing)
     const int last_row = n_rows > 0 ? n_rows - 1 : 0;
     const int row = lane < n_rows ? lane : last_row;  // idle lanes shadow the last row
-    const uint64_t h = it.first_hop + row;
+    const uint64_t h = it.first_hop + static_cast<uint64_t>(row) * rstride;
     constexpr unsigned FB = (INF == 1 ? 2 : INF == 2 ? 3 : 4) * NCH;  // frame bytes
     constexpr unsigned PB = 16 * FB;            // piece bytes
     constexpr int NCK = PB / 16;                // 16-byte chunks per piece
@@ -390,7 +402,7 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
     constexpr int NDMA = MC ? (NS + WGW - 1) / WGW : NCK;  // DMA instructions per wave and piece set (64 rows); stereo: 8, 4 or 6
     constexpr int LPP = PB / 16;                // lanes per piece (stereo)
     constexpr int kMcPiece = 64 * NS * 16;      // MC: one piece buffer
-    const char *wave_base = static_cast<const char *>(t.pcm) + it.frame0 * static_cast<unsigned long long>(FB);
+    const char *wave_base = static_cast<const char *>(t.pcm) + (it.frame0 - phi) * static_cast<unsigned long long>(FB);  // (the grid's start)
     char *lbuf = MC ? smem : smem + wave * kPieceLds;  // MC: [2][kMcPiece], piece k in half k & 1
     char *abuf = smem + (MC ? 2 * kMcPiece : kFusedWaves * kPieceLds);    // [2][9 KiB]: step k reads half k&1 (or the resident rotations, below)
     char *gbuf = abuf + kCoefArea;        // [2][1 KiB]: step k reads half k&1
@@ -403,11 +415,14 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
 #else
     const bool resident = DO_TP && MT <= 2 && r.tp_np == 1;
 #endif
-    const char *gsrc = reinterpret_cast<const char *>(r.g);  // 512 B (16 frames x 4 doubles) per step
+    // 512 B (16 frames x 4 doubles) per step; grid frame i of step k is frame 16 k + i - phi of the row (the table has 16 entries of
+    // padding in front: the slice of step 0 starts phi entries before it)
+    const char *gsrc = reinterpret_cast<const char *>(r.g) - phi * 32u;
     const unsigned lane16 = static_cast<unsigned>(lane) * 16u;
-    const int T_full = static_cast<int>(hop / 16), rem = static_cast<int>(hop % 16);
-    // steps >= k_short accumulate only q[2], q[3] (RateDev::q_n0)
-    const int k_short = r.q_n0 < hop ? static_cast<int>(r.q_n0 / 16) : T + 1;
+    const int T_full = static_cast<int>(hopg / 16), rem = static_cast<int>(hopg % 16);
+    // steps >= k_short accumulate only q[2], q[3] (RateDev::q_n0; with a shifted grid the first step that lies wholly behind
+    // q_n0 is one later, and the phases of the loop start at multiples of 3)
+    const int k_short = r.q_n0 < hop ? static_cast<int>(r.q_n0 / 16) + (phi ? 3 : 0) : T + 1;
 
     // ---- DMA geometry: instruction j moves LDS slots 8j..8j+7 (one 128-byte piece each, 8 lanes per piece)
     // (s16: instruction j moves slots 16j..16j+15, four lanes per 64-byte piece; position p of row l holds source chunk
@@ -421,7 +436,7 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
             const int pos = 64 * (j * WGW + wave) + lane;
             const int slot = pos / NS, chunk = pos - slot * NS;
             const int srow = slot < n_rows ? slot : last_row;
-            dma_off[j] = (slot < 64 && chunk < NCK) ? static_cast<unsigned>(srow) * hop * FB + static_cast<unsigned>(chunk) * 16u : ~0u;
+            dma_off[j] = (slot < 64 && chunk < NCK) ? static_cast<unsigned>(srow) * hop * FB + static_cast<unsigned>(chunk) * 16u : ~0u;  // (row_stride 1)
         } else {
             // (s24: 384 lane slots = 64 rows x 6 chunks, rows do not end with the instruction; position p of row l holds
             // source chunk (p - ((l >> 3) & 1)) mod 6: rows l and l + 8, whose 96-byte images start in the same bank, are a
@@ -431,7 +446,7 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
             const int chunk = INF == 2 ? (gi % 6 + 6 - ((slot >> 3) & 1)) % 6
                             : INF == 1 ? ((lane & 3) ^ ((slot >> 2) & 3)) : ((lane & 7) ^ ((slot >> 1) & 7));
             const int srow = slot < n_rows ? slot : last_row;
-            dma_off[j] = static_cast<unsigned>(srow) * hop * FB + static_cast<unsigned>(chunk) * 16u;
+            dma_off[j] = static_cast<unsigned>(srow) * rstride * hop * FB + static_cast<unsigned>(chunk) * 16u;
             // dbg 128 (experiments, results wrong): every row's pieces start on a 128-byte line -- what line-aligned pieces would buy
             if (HR_DBG(dbg, 128)) dma_off[j] = ((static_cast<unsigned>(srow) * hop * FB) & ~127u) + static_cast<unsigned>(chunk) * 16u;
         }
@@ -502,7 +517,7 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
 #pragma unroll
     for (int c = 0; c < 2; c++) ks[c] = KState{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     {
-        const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * hop * FB);
+        const float *rowp = reinterpret_cast<const float *>(wave_base + static_cast<size_t>(row) * rstride * hop * FB);  // (the grid's first frame)
         const unsigned *rowq = reinterpret_cast<const unsigned *>(rowp);  // s16: one dword per frame
         const uint8_t *rowb = reinterpret_cast<const uint8_t *>(rowp);    // s24: six bytes per frame
         const char *rowc = reinterpret_cast<const char *>(rowp);          // MC: FB bytes per frame
@@ -632,7 +647,7 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
 
     // tile bookkeeping (wave-uniform): the coefficient pattern of tile t is t mod NP
     const int NP = r.tp_np;
-    int pat = 0;  // pattern of the next tile whose coefficients are fetched
+    int pat = ALIGNED_OK ? it.pat0 : 0;  // pattern of the next tile whose coefficients are fetched (a shifted grid starts inside the sequence)
 
     // coefficient chunk ks of the tile screened at step k+1 pairs with piece k-1+ks, slot (k+2+ks) mod 3
     // This wave's share (chunks i with i mod 4 == wave) of the coefficients of the tile that step k+1 screens,
@@ -769,6 +784,22 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
                 v[c].y = 2 * c < lim ? v[c].y : 0.0f;
                 v[c].z = 2 * c + 1 < lim ? v[c].z : 0.0f;
                 v[c].w = 2 * c + 1 < lim ? v[c].w : 0.0f;
+            }
+        }
+        // a shifted grid: the row starts phi frames into piece 0.  Its K-weighting starts there, from the two frames in front of
+        // it, frame by frame straight from LDS (the fused block below takes whole pieces: this step only screens)
+        if constexpr (ALIGNED_OK && DO_KW && !SHORT) {
+            if (phi && k == 0) {
+                auto frame = [&](unsigned i) { return *reinterpret_cast<const float2 *>(my_lds + (((i >> 1) ^ rd_swz) * 16) + (i & 1) * 8); };
+                const float2 xm1 = frame(phi - 1), xm2 = frame(phi - 2);  // (phi is even and not 0 here)
+                ks[0].x1 = static_cast<double>(xm1.x); ks[1].x1 = static_cast<double>(xm1.y);
+                ks[0].x2 = static_cast<double>(xm2.x); ks[1].x2 = static_cast<double>(xm2.y);
+                for (unsigned i = phi; i < 16; i++) {
+                    const float2 x = frame(i);
+                    const G4 g4 = lds_g4(gbuf + i * 32);
+                    kw_sample(ks[0], kc, x.x, g4);
+                    kw_sample(ks[1], kc, x.y, g4);
+                }
             }
         }
         // the last piece of a hop may be partial (44.1 kHz: 4410 = 275*16 + 10): K-weight its frames one at a
@@ -1075,7 +1106,7 @@ __device__ __forceinline__ void fused_body(char *smem, const TrackDesc *__restri
                         for (int q = 0; q < 4; q++) hist[a][ch][nt][q] = drop ? 0u : hist[a][ch][nt][q];
             }
         }
-        const bool fused_step = DO_KW && k < T_full;
+        const bool fused_step = DO_KW && k < T_full && !(phi && k == 0);
         if (fused_step) {
             fused_block();
         } else {

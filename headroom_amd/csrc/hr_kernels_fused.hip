@@ -511,10 +511,13 @@ __global__ void __launch_bounds__(256) k_refine_cands(const TrackDesc *__restric
             if (src < 0) continue;
             const int ch = ex & 1u, crow = (ex >> 1) & 63u, mt = (ex >> 7) & 3u, half = (ex >> 9) & 1u;
             const int tile = static_cast<int>(ex >> 10);
-            const long num0 = 16L * tile * P, num1 = 16L * (tile + 1) * P;
+            // (a row with a shifted piece grid, FusedItem::phi: its tile t starts phi frames before frame 16 t of the row; counted
+            // from the hop in front of the row, which starts at phase 0 of the bank like every hop, nothing is negative)
+            const long shift = it.phi ? static_cast<long>(it.row_len) - it.phi : 0;
+            const long num0 = (16L * tile + shift) * P, num1 = (16L * (tile + 1) + shift) * P;
             const int m_lo = static_cast<int>((num0 + step - 1) / step);
             const int count = static_cast<int>((num1 + step - 1) / step) - m_lo;
-            const int64_t row_frame0 = static_cast<int64_t>(it.frame0) + static_cast<int64_t>(crow) * it.row_len;
+            const int64_t row_frame0 = static_cast<int64_t>(it.frame0) + static_cast<int64_t>(crow) * it.row_stride * it.row_len - (it.phi ? it.row_len : 0);
             const int i = lane & 15;
             const int rowidx = 32 * mt + 4 * half + (i & 3) + 8 * (i >> 2);
             if (rowidx >= count) continue;

@@ -75,7 +75,9 @@ typedef struct hr_config {
                            per track and launch; same results, for tests and timing); 5 = as 0, but 5.1 / 7.1 tracks are
                            split into stereo planes first instead of being read directly (the path of rounds 1-2; same
                            results bit for bit, for tests and A/B timing); 6 = as 0, but a 5.1 track read directly keeps
-                           the three-wave workgroup where 0 takes the four-wave one (same results bit for bit) */
+                           the three-wave workgroup where 0 takes the four-wave one (same results bit for bit); 7 = as 0, but no
+                           row of a stereo f32 track gets a piece grid shifted onto cache lines (44.1 kHz and its multiples;
+                           same counts and peaks, loudness equal to the 14th digit) */
     void *stream;       /* hipStream_t to run on, or NULL for a stream owned by the context */
     uint64_t stage_bytes; /* device staging for host-resident PCM per launch group; 0 = default (1 GiB).  A batch that
                              needs more is measured group by group, the copies of the next group (on a stream of
