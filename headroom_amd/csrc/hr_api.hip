@@ -595,8 +595,10 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     constexpr uint64_t kAlignedBlock = 512;
 #ifdef HR_EXPERIMENTS  // HR_ALIGN_MODE=1: strided items whose grids are NOT shifted (what the stride alone costs: +4.4 % kernel time)
     static const int align_mode = std::getenv("HR_ALIGN_MODE") ? std::atoi(std::getenv("HR_ALIGN_MODE")) : 0;
+    static const size_t align_super = std::getenv("HR_ALIGN_SUPER") ? static_cast<size_t>(std::atol(std::getenv("HR_ALIGN_SUPER"))) : 8;
 #else
     constexpr int align_mode = 0;
+    constexpr size_t align_super = 8;
 #endif
     auto phi_of = [&](const TrackDesc &d, uint64_t j) { return align_mode == 1 ? 0u : static_cast<uint32_t>(((j * d.hop * 8ull) % 128) / 8); };
     // per rate and phi / 2: the tile pattern a grid that starts phi frames before a hop begins with (16 pat0 + phi is a whole
@@ -625,32 +627,46 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     for (int cls = 0; cls < kFusedClasses; cls++) {
         class_off[cls] = fitems.size();
-        for (size_t rp = 0; rp < 10 * n_rates; rp++) {  // (rate, whole-hop rows), (rate, shorter rows), (rate, aligned rows of phi = 0, 2 .. 14)
-            const size_t ri = rp / 10;
-            const bool shorter = rp % 10 == 1;
-            const int al_phi = rp % 10 >= 2 ? static_cast<int>(2 * (rp % 10 - 2)) : -1;
+        for (size_t rp = 0; rp < 3 * n_rates; rp++) {  // (rate, whole-hop rows), (rate, shorter rows), (rate, rows with shifted grids)
+            const size_t ri = rp / 3;
+            const bool shorter = rp % 3 == 1;
             const size_t run_begin = fitems.size();
+            if (rp % 3 == 2) {
+                // The (track, block) pairs of the rate four at a time: for each of the eight offsets a workgroup of the four
+                // pairs' items with that offset.  Eight consecutive workgroups then read the same four blocks completely --
+                // rows 8 hops apart leave seven eighths of a block to the other seven items, and with a run per offset those
+                // came a whole sweep over the launch's tracks later (the strided items alone cost 4.4 % that way).
+                std::vector<std::pair<uint32_t, uint64_t>> pairs;
+                for (const uint32_t i : by_class_rate[static_cast<size_t>(cls) * n_rates + ri])
+                    for (uint64_t b = 0; b < al_blocks[i]; b++) pairs.emplace_back(i, b);
+                // (Workgroups go to the XCDs in turn, so the eight workgroups of four pairs are put eight apart: they meet in one
+                // L2, where the line that ends hop h and starts hop h + 1 is fetched once for both.)
+                const size_t n_chunks = (pairs.size() + kFusedWaves - 1) / kFusedWaves;
+                for (size_t sc = 0; sc < n_chunks; sc += align_super)
+                    for (uint64_t j = 0; j < 8; j++)
+                        for (size_t c = sc; c < std::min(sc + align_super, n_chunks); c++)
+                            for (size_t w = 0; w < static_cast<size_t>(kFusedWaves); w++) {
+                                const size_t pi = c * kFusedWaves + w;
+                                const bool real = pi < pairs.size();
+                                const auto &pr = pairs[real ? pi : pairs.size() - 1];  // (padding: a copy of the last pair's item, no rows)
+                                const TrackDesc &d = g.descs[pr.first];
+                                const uint32_t phi = phi_of(d, j);
+                                FusedItem it{};
+                                it.track = pr.first;
+                                it.n_rows = real ? 64 : 0;
+                                it.first_hop = pr.second * kAlignedBlock + j;
+                                it.frame0 = it.first_hop * d.hop;
+                                it.row_len = d.hop;
+                                it.row_stride = 8;
+                                it.phi = static_cast<uint16_t>(phi);
+                                it.pat0 = static_cast<uint32_t>(pat0_tab[d.rate_idx * 8 + phi / 2]);
+                                fitems.push_back(it);
+                            }
+                continue;
+            }
             for (const uint32_t i : by_class_rate[static_cast<size_t>(cls) * n_rates + ri]) {
                 const TrackDesc &d = g.descs[i];
                 const uint64_t nb = al_blocks[i];
-                if (al_phi >= 0) {
-                    for (uint64_t j = 0; j < 8 && nb; j++) {
-                        if (phi_of(d, j) != static_cast<uint32_t>(al_phi)) continue;
-                        for (uint64_t b = 0; b < nb; b++) {
-                            FusedItem it{};
-                            it.track = i;
-                            it.n_rows = 64;
-                            it.first_hop = b * kAlignedBlock + j;
-                            it.frame0 = it.first_hop * d.hop;
-                            it.row_len = d.hop;
-                            it.row_stride = 8;
-                            it.phi = static_cast<uint16_t>(al_phi);
-                            it.pat0 = static_cast<uint32_t>(pat0_tab[d.rate_idx * 8 + al_phi / 2]);
-                            fitems.push_back(it);
-                        }
-                    }
-                    continue;
-                }
                 // this section's rows: record rows [r0, r1) from frame f0 on, `len` frames each; the track's last section
                 // also holds the rows behind the last hop, and loses the final hop's row when that one stays generic
                 const bool has_sub = sub_from[i] < d.n_hops;
