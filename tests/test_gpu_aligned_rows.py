@@ -81,6 +81,16 @@ def test_hop_energies_with_shifted_grids(oracle, meters, fs, seconds):
     assert np.max(np.abs(H / H7 - 1)) < 1e-12
 
 
+@pytest.mark.parametrize("fs,seconds", [(176400, 53.0), (12345, 70.0), (22050, 60.0), (14700, 60.0)])
+def test_other_rates_whose_hops_are_off_the_line_grid(oracle, meters, fs, seconds):
+    """176.4 kHz (offsets 0 / 8 frames), rates libswresample interpolates between phases (12 345 Hz: K-weighting on the fused
+    kernel, peaks on the generic one), 22.05 kHz (odd offsets: rows stay as they were), 14.7 kHz (hop 1470)."""
+    pcm = music_like(fs, fs, seconds, ragged=19)
+    got = meters(0).analyze(pcm, fs)
+    same(got, meters(7).analyze(pcm, fs))
+    against_oracle(oracle, got, pcm, fs)
+
+
 @pytest.mark.parametrize("tp", ["swr192k", "bs1770", "sample"])
 @pytest.mark.parametrize("fs,seconds", [(44100, 60.3), (44100, 154.7), (88200, 55.0)])
 def test_shifted_grids_equal_plain_rows_and_oracle(oracle, meters, fs, seconds, tp):
