@@ -1051,6 +1051,13 @@ int overflow_redo(hr_ctx *ctx, Group &g, bool *relaunched)
             for (size_t w = 0; w < run.n_items * run.wpi && run.list_off + w < cnt.size(); w++) {
                 const FusedItem &it = ctx->h_fitems[run.item_off + w / run.wpi];
                 if (!(cnt[run.list_off + w] & kCandOverflowBit) || !it.n_rows || !ctx->h_ftp[it.track] || (ovf[it.track] & 1u) || g.fmts[it.track] != f) continue;
+                if (it.row_stride > 1) {  // (rows with shifted piece grids: the wave's hops are row_stride apart, each redone on its own)
+                    for (uint32_t rr = 0; rr < it.n_rows; rr++) {
+                        const uint64_t f0 = it.frame0 + static_cast<uint64_t>(rr) * it.row_stride * it.row_len;
+                        add_range(it.track, f0, std::min<uint64_t>(f0 + it.row_len, ctx->h_fend[it.track]), 0);
+                    }
+                    continue;
+                }
                 add_range(it.track, it.frame0, std::min<uint64_t>(it.frame0 + static_cast<uint64_t>(it.n_rows) * it.row_len, ctx->h_fend[it.track]),
                           static_cast<uint32_t>(2 * (w % run.wpi)));
             }
