@@ -1555,7 +1555,10 @@ try {
     // FRAMES (one item per 8192 positions for the generic peak kernels and, worst case, for the exact redo of every fused
     // wave), not with the hops -- a mono or multichannel track at 384 / 768 kHz inside the hop limit is far longer in frames.
     {
-        const uint64_t ch = track->channels, waves = (hops / 64 + 8) * std::max<uint64_t>(1, ch / 2), per_span = track->frames / kPeakSpan + hops / 256 + 16;
+        // (waves: the items of rows with shifted piece grids come in workgroups of four per offset, up to 24 of them padding;
+        // per_span: the exact redo of such an item is one work item per hop)
+        const uint64_t ch = track->channels, waves = (hops / 64 + 8 + 32) * std::max<uint64_t>(1, ch / 2),
+                       per_span = track->frames / kPeakSpan + hops / 256 + 16 + hops / 2;
         const uint64_t need = (hops + kPreRec + 8) * ch * sizeof(HopRec) + (hops + kPreHop + 8) * ch * sizeof(double) + (hops + 1) * sizeof(double) +
                               2 * kEbuBins * sizeof(uint32_t) + waves * (fused_cand_bytes(1) + sizeof(FusedItem) + sizeof(unsigned)) +
                               (2 * per_span + 2 * ch) * sizeof(WorkItem) + (hops * ch / 256 + 2) * sizeof(WorkItem) +

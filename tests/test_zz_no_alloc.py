@@ -157,3 +157,15 @@ def test_noalloc_limits_that_grow_with_frames():
         rc, r = m.analyze_device_noalloc(spec)
         assert rc == hr.OK
         same(r, ref)
+        # the same at 44.1 kHz, where the rows of whole blocks of 512 hops have shifted piece grids and the redo of such a wave
+        # is one work item per hop
+        fs = 44100
+        n = fs * 600
+        tt = torch.arange(n, dtype=torch.float64, device="cuda:0")
+        tone = torch.sin(tt * (2 * math.pi * 997.0 / fs)).to(torch.float32)
+        pcm = torch.stack([tone, 0.5 * tone], dim=1).contiguous()
+        spec = hr.TrackSpec(pcm, fs)
+        ref = m.analyze_batch([spec])[0]
+        rc, r = m.analyze_device_noalloc(spec)
+        assert rc == hr.OK
+        same(r, ref)
