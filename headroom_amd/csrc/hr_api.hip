@@ -592,14 +592,17 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     // phi(j) frames early, on a line; what is left of the track behind its last whole block stays as it was.  The four waves of
     // a workgroup share the coefficient tiles and the carry-table slices, so every phi is a run of its own.
     // hr_config.engine = 7 keeps all rows as they were (A/B and tests).
-    constexpr uint64_t kAlignedBlock = 512;
 #ifdef HR_EXPERIMENTS  // HR_ALIGN_MODE=1: strided items whose grids are NOT shifted (what the stride alone costs: +4.4 % kernel time)
     static const int align_mode = std::getenv("HR_ALIGN_MODE") ? std::atoi(std::getenv("HR_ALIGN_MODE")) : 0;
     static const size_t align_super = std::getenv("HR_ALIGN_SUPER") ? static_cast<size_t>(std::atol(std::getenv("HR_ALIGN_SUPER"))) : 8;
+    // HR_ALIGN_STRIDE (with HR_ALIGN_MODE=1 only: the offsets repeat every 8 hops): hops between the rows of a strided item
+    static const uint64_t kAlignedStride = align_mode == 1 && std::getenv("HR_ALIGN_STRIDE") ? static_cast<uint64_t>(std::atol(std::getenv("HR_ALIGN_STRIDE"))) : 8;
 #else
     constexpr int align_mode = 0;
     constexpr size_t align_super = 8;
+    constexpr uint64_t kAlignedStride = 8;
 #endif
+    const uint64_t kAlignedBlock = 64 * kAlignedStride;
     auto phi_of = [&](const TrackDesc &d, uint64_t j) { return align_mode == 1 ? 0u : static_cast<uint32_t>(((j * d.hop * 8ull) % 128) / 8); };
     // per rate and phi / 2: the tile pattern a grid that starts phi frames before a hop begins with (16 pat0 + phi is a whole
     // number of input steps); -1: there is none
@@ -621,7 +624,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
             (reinterpret_cast<uintptr_t>(d.pcm) & 127))
             continue;
         bool ok = true;
-        for (uint64_t j = 0; j < 8 && ok; j++) ok = phi_of(d, j) % 2 == 0 && pat0_tab[d.rate_idx * 8 + phi_of(d, j) / 2] >= 0;
+        for (uint64_t j = 0; j < kAlignedStride && ok; j++) ok = phi_of(d, j) % 2 == 0 && pat0_tab[d.rate_idx * 8 + phi_of(d, j) / 2] >= 0;
         const uint64_t limit = sub_from[i] < d.n_hops ? sub_from[i] : d.n_hops - 1;  // (never the track's final row)
         if (ok) al_blocks[i] = limit / kAlignedBlock;
     }
@@ -643,7 +646,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                 // L2, where the line that ends hop h and starts hop h + 1 is fetched once for both.)
                 const size_t n_chunks = (pairs.size() + kFusedWaves - 1) / kFusedWaves;
                 for (size_t sc = 0; sc < n_chunks; sc += align_super)
-                    for (uint64_t j = 0; j < 8; j++)
+                    for (uint64_t j = 0; j < kAlignedStride; j++)
                         for (size_t c = sc; c < std::min(sc + align_super, n_chunks); c++)
                             for (size_t w = 0; w < static_cast<size_t>(kFusedWaves); w++) {
                                 const size_t pi = c * kFusedWaves + w;
@@ -657,7 +660,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
                                 it.first_hop = pr.second * kAlignedBlock + j;
                                 it.frame0 = it.first_hop * d.hop;
                                 it.row_len = d.hop;
-                                it.row_stride = 8;
+                                it.row_stride = static_cast<uint16_t>(kAlignedStride);
                                 it.phi = static_cast<uint16_t>(phi);
                                 it.pat0 = static_cast<uint32_t>(pat0_tab[d.rate_idx * 8 + phi / 2]);
                                 fitems.push_back(it);
