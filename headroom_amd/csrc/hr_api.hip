@@ -483,7 +483,7 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
         // Whole rounds of whole-hop waves: the waves beyond the last full round of the 2048 slots would run as a partial
         // round of long waves; their hops become shorter rows instead (64 hops = one wave less per step of this loop),
         // which fill the last rounds in finer grain (measured: 300 tracks 6.88 -> 6.32 ms, 500 and 1000 tracks -0.7 %).
-        if (!everywhere && (ctx->cfg.engine == 0 || ctx->cfg.engine == 5)) {
+        if (!everywhere && (ctx->cfg.engine == 0 || ctx->cfg.engine >= 5)) {  // (5, 6, 7: as 0 but for one choice each)
             uint64_t whole = 0;
             for (size_t i = 0; i < nt; i++)
                 if (cost[i].waves[0]) whole += (sub_from[i] + 63) / 64 * wpi_of(i);
@@ -630,11 +630,14 @@ int run_measure(hr_ctx *ctx, Group &g, bool do_peaks, bool do_combine = true)
     }
     for (int cls = 0; cls < kFusedClasses; cls++) {
         class_off[cls] = fitems.size();
-        for (size_t rp = 0; rp < 3 * n_rates; rp++) {  // (rate, whole-hop rows), (rate, shorter rows), (rate, rows with shifted grids)
+        // (rate, rows with shifted grids), (rate, whole-hop rows), (rate, shorter rows): the long items first -- workgroups start
+        // in launch order, and the short items are there to fill the launch's last round in finer grain (with the shifted-grid
+        // items behind them the last round was all long items again: +1.6 % kernel time)
+        for (size_t rp = 0; rp < 3 * n_rates; rp++) {
             const size_t ri = rp / 3;
-            const bool shorter = rp % 3 == 1;
+            const bool shorter = rp % 3 == 2;
             const size_t run_begin = fitems.size();
-            if (rp % 3 == 2) {
+            if (rp % 3 == 0) {
                 // The (track, block) pairs of the rate four at a time: for each of the eight offsets a workgroup of the four
                 // pairs' items with that offset.  Eight consecutive workgroups then read the same four blocks completely --
                 // rows 8 hops apart leave seven eighths of a block to the other seven items, and with a run per offset those

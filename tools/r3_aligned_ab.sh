@@ -2,7 +2,7 @@
 # A/B of the line-aligned rows (engine 0) against rows as they were (engine 7), 500 tracks of the headline workload;
 # HR_ALIGN_MODE=1 (experiment): strided items without the grid shift
 mkdir -p gpurun_out/r3
-for cfg in "7 0" "0 0" "7 0" "0 0"; do
+for cfg in "7 0" "0 0" "7 0" "0 0" "7 0" "0 0" "7 0" "0 0" "7 0" "0 0"; do
   set -- $cfg
   HR_ALIGN_MODE=$2 timeout -k 10 200 python bench.py --tracks 1000 --steps 5 --warmup 2 --no-cpu-baseline --engine $1 > gpurun_out/r3/p_engine$1_$2.json 2> gpurun_out/r3/p_engine$1_$2.err || { tail -5 gpurun_out/r3/p_engine$1_$2.err; exit 1; }
   python - <<PY
