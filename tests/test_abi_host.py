@@ -53,7 +53,8 @@ def test_shipped_library_has_no_experiment_switches():
     """Timing experiments (HR_ABLATE and friends make the results wrong on purpose) compile only into
     libheadroom_hip_exp.so (-DHR_EXPERIMENTS); the shipped library must not even contain their names."""
     data = open(hr.LIB_PATH, "rb").read()
-    for name in (b"HR_ABLATE", b"HR_FUSED_SPLIT", b"HR_SERIAL_TAIL", b"HR_WAVE_MAP", b"HR_SPLIT_GEOM", b"HR_EXP_", b"k_fused_split"):
+    for name in (b"HR_ABLATE", b"HR_FUSED_SPLIT", b"HR_SERIAL_TAIL", b"HR_WAVE_MAP", b"HR_SPLIT_GEOM", b"HR_EXP_", b"k_fused_split",
+                 b"HR_ALIGN_MODE", b"HR_ALIGN_SUPER", b"HR_ALIGN_STRIDE", b"HR_HOST_TIMING"):
         assert name not in data, name
 
 
